@@ -1,0 +1,214 @@
+"""Parameter inventory and seeded synthetic inputs for the head-render path.
+
+The reference ships neither checkpoints nor camera intrinsics (SURVEY.md
+header), so every number this repo produces is on seeded random weights and a
+synthetic camera.  This module is the single source of those inputs: the golden
+fixture generator (tools/gen_golden.py) loads `make_state_dict()` into the
+reference module with a strict `load_state_dict`, and the tests / bench feed the
+same tensors to the HIP path.  Everything is generated on the CPU with an
+explicit `torch.Generator`, so it is identical here and on the GPU box.
+
+Reference shapes followed (not copied):
+  MLP layer shapes / init rules ....... NetWorks/models.py:29-59
+  neural renderer layer shapes ........ NetWorks/neural_renderer.py:49-69
+  pixel-shuffle block shapes .......... NetWorks/PixelShuffleUpsample.py:29-33
+  ray grid ............................ Utils/RenderUtils.py:31-43
+  inverse intrinsics form ............. XGaze_utils/data_loader_xgaze_new.py:1092-1097
+  default camera ...................... Utils/RenderUtils.py:53-99
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+PE_FREQS = 10
+PE_DIM = 3 + 6 * PE_FREQS  # 63 (reference: HeadNeRFNet.py:27-28,50)
+
+
+def n_blocks(opt):
+    return int(math.log2(opt.pred_img_size) - math.log2(opt.featmap_size))
+
+
+def mlp_dims(opt, include_gaze=False, eye_gaze_dim=2, audio_dim=64):
+    """Channel bookkeeping of the latent-conditioned MLP."""
+    shape_dim = opt.iden_code_dims + opt.expr_code_dims + (eye_gaze_dim if include_gaze else 0)
+    appea_dim = opt.text_code_dims + opt.illu_code_dims
+    vp = PE_DIM + shape_dim
+    return {
+        "H": opt.mlp_hidden_nchannels,
+        "C": opt.featmap_nc,
+        "shape_dim": shape_dim,
+        "appea_dim": appea_dim,
+        "audio_dim": audio_dim,
+        "vp": vp,
+        "in0": vp + audio_dim,
+        "in5": vp + opt.mlp_hidden_nchannels,
+        "in_rgb1": opt.mlp_hidden_nchannels + appea_dim,
+    }
+
+
+def param_specs(opt, include_gaze=False, eye_gaze_dim=2, audio_dim=64):
+    """Ordered name -> (shape, init_kind, is_buffer).
+
+    init_kind: "xavier" | "default_w" | "default_b" | "zero" | "ones" | "blur"
+    Key names are the reference module's state-dict keys.
+    """
+    d = mlp_dims(opt, include_gaze, eye_gaze_dim, audio_dim)
+    H, C = d["H"], d["C"]
+    specs = OrderedDict()
+
+    def conv(prefix, cin, cout, w_init, b_init="default_b"):
+        specs[prefix + ".weight"] = ((cout, cin, 1, 1), w_init, False)
+        specs[prefix + ".bias"] = ((cout,), b_init, False)
+
+    p = "fg_CD_predictor."
+    conv(p + "FeaExt_module_0", d["in0"], H, "default_w")
+    for i in range(1, 8):
+        conv(p + "FeaExt_module_%d" % i, d["in5"] if i == 5 else H, H, "xavier")
+    conv(p + "density_module", H, 1, "xavier", "zero")
+    conv(p + "RGB_layer_0", H, H, "xavier")
+    conv(p + "RGB_layer_1", d["in_rgb1"], H // 2, "default_w")
+    conv(p + "RGB_layer_2", H // 2, C, "default_w")
+
+    nb = n_blocks(opt)
+    fs = opt.featmap_size
+    q = "neural_render."
+    specs[q + "bg_featmap"] = ((1, C, fs, fs), "ones" if opt.bg_type == "white" else "zero", False)
+    for i in range(nb):
+        ci = max(C // (2 ** i), 32)
+        conv(q + "feat_upsample_list.%d.layer_1" % i, ci, ci * 2, "default_w")
+        conv(q + "feat_upsample_list.%d.layer_2" % i, ci * 2, ci * 4, "default_w")
+        specs[q + "feat_upsample_list.%d.blur_layer.f" % i] = ((3,), "blur", True)
+    specs[q + "rgb_upsample.1.f"] = ((3,), "blur", True)
+    conv(q + "feat_2_rgb_list.0", C, 3, "default_w")
+    for i in range(nb):
+        conv(q + "feat_2_rgb_list.%d" % (i + 1), max(C // (2 ** (i + 1)), 32), 3, "default_w")
+    for i in range(nb):
+        conv(q + "feat_layers.%d" % i, max(C // (2 ** i), 32), max(C // (2 ** (i + 1)), 32), "default_w")
+    return specs
+
+
+def init_tensor(shape, kind, gen, fan_in_of_weight=None):
+    """One tensor under the reference's init rule for its layer."""
+    if kind == "zero":
+        return torch.zeros(shape)
+    if kind == "ones":
+        return torch.ones(shape)
+    if kind == "blur":
+        return torch.tensor([1.0, 2.0, 1.0])
+    if kind == "xavier":
+        cout, cin = shape[0], shape[1]
+        a = math.sqrt(6.0 / (cin + cout))
+    elif kind == "default_w":  # kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+        a = 1.0 / math.sqrt(shape[1])
+    elif kind == "default_b":
+        a = 1.0 / math.sqrt(fan_in_of_weight)
+    else:
+        raise ValueError(kind)
+    return (torch.rand(shape, generator=gen) * 2.0 - 1.0) * a
+
+
+def make_state_dict(opt, seed=0, include_gaze=False, eye_gaze_dim=2, audio_dim=64, bg_noise=0.0):
+    """Seeded random weights with the reference's per-layer init distributions.
+
+    bg_noise > 0 perturbs the learned background feature map away from its
+    all-ones initial value so that the merge seam is exercised non-trivially.
+    """
+    gen = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    last_fan_in = None
+    for name, (shape, kind, _buf) in param_specs(opt, include_gaze, eye_gaze_dim, audio_dim).items():
+        if name.endswith(".weight"):
+            last_fan_in = shape[1]
+        sd[name] = init_tensor(shape, kind, gen, last_fan_in)
+    if bg_noise > 0.0:
+        k = "neural_render.bg_featmap"
+        sd[k] = sd[k] + bg_noise * torch.randn(sd[k].shape, generator=gen)
+    return sd
+
+
+def state_dict_checksum(sd):
+    """Cheap drift detector stored next to every fixture."""
+    tot, asum = 0.0, 0.0
+    for v in sd.values():
+        v64 = v.double()
+        tot += float(v64.sum())
+        asum += float(v64.abs().sum())
+    return [tot, asum]
+
+
+def ray_grid(fs, n_side=None):
+    """Integer pixel-centre ray grid, x = i % w, y = i // w (no +0.5).
+
+    Returns batch_xy [1,2,N_r] float32 and batch_uv [1,N_r,2] (unused by the net).
+    n_side lets the 'literal' reading cast rays on an n_side x n_side grid while
+    keeping intrinsics expressed in that grid's pixel units.
+    """
+    w = n_side or fs
+    idx = torch.arange(w * w)
+    x = (idx % w).float()
+    y = torch.div(idx, w, rounding_mode="floor").float()
+    xy = torch.stack([x, y], dim=0).unsqueeze(0)
+    uv = torch.stack([x / float(w), y / float(w)], dim=-1).unsqueeze(0)
+    return xy, uv
+
+
+def inv_intrinsics(grid, batch):
+    """K^-1 for focal 1200*grid/512 and principal point grid/2."""
+    f = 1200.0 * grid / 512.0
+    c = grid / 2.0
+    k = torch.tensor([[1.0 / f, 0.0, -c / f], [0.0, 1.0 / f, -c / f], [0.0, 0.0, 1.0]])
+    return k.unsqueeze(0).repeat(batch, 1, 1).contiguous()
+
+
+def cameras(batch, yaw_range=0.3, seed=99):
+    """c2w rotation diag(1,-1,-1) (optionally yawed about world y) and T=(0,0,12)."""
+    gen = torch.Generator().manual_seed(seed)
+    base = torch.diag(torch.tensor([1.0, -1.0, -1.0]))
+    Rs, Ts = [], []
+    for _ in range(batch):
+        yaw = (torch.rand((), generator=gen).item() * 2.0 - 1.0) * yaw_range
+        cy, sy = math.cos(yaw), math.sin(yaw)
+        Ry = torch.tensor([[cy, 0.0, sy], [0.0, 1.0, 0.0], [-sy, 0.0, cy]])
+        Rs.append(Ry @ base)
+        # keep the camera on the orbit sphere so the head stays in the slab
+        Ts.append(Ry @ torch.tensor([[0.0], [0.0], [12.0]]))
+    return torch.stack(Rs).contiguous(), torch.stack(Ts).contiguous()
+
+
+def latents(batch, shape_dim=179, appea_dim=127, audio_dim=64, first_frame=0):
+    """0.5*N(0,1) codes, one generator per frame index (seed 1234+frame)."""
+    sh, ap, au = [], [], []
+    for b in range(batch):
+        gen = torch.Generator().manual_seed(1234 + first_frame + b)
+        sh.append(0.5 * torch.randn(shape_dim, generator=gen))
+        ap.append(0.5 * torch.randn(appea_dim, generator=gen))
+        au.append(0.5 * torch.randn(max(audio_dim, 1), generator=gen)[:audio_dim])
+    return torch.stack(sh), torch.stack(ap), torch.stack(au)
+
+
+def stratified_noise(batch, n_rays, n_samples, seed=7):
+    """The per-edge jitter tensor the train mode consumes."""
+    gen = torch.Generator().manual_seed(seed)
+    return torch.rand(batch, n_rays, n_samples + 1, generator=gen)
+
+
+def frame_inputs(opt, batch, n_side=None, yaw_range=0.3, include_gaze=False, eye_gaze_dim=2,
+                 audio_dim=64, first_frame=0):
+    """All forward() inputs for `batch` synthetic frames, keyed by the reference's kwarg names."""
+    grid = n_side or opt.featmap_size
+    d = mlp_dims(opt, include_gaze, eye_gaze_dim, audio_dim)
+    xy, uv = ray_grid(opt.featmap_size, n_side)
+    R, T = cameras(batch, yaw_range)
+    sh, ap, au = latents(batch, d["shape_dim"], d["appea_dim"], audio_dim, first_frame)
+    return {
+        "batch_xy": xy.expand(batch, -1, -1),
+        "batch_uv": uv.expand(batch, -1, -1),
+        "audiostyle": au,
+        "bg_code": None,
+        "shape_code": sh,
+        "appea_code": ap,
+        "batch_Rmats": R,
+        "batch_Tvecs": T,
+        "batch_inv_inmats": inv_intrinsics(grid, batch),
+    }

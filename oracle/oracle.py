@@ -1,0 +1,174 @@
+"""ctypes binding of the CPU restatement (oracle/n3dt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MLP_ORDER = ["FeaExt_module_%d" % i for i in range(8)] + ["density_module", "RGB_layer_0", "RGB_layer_1", "RGB_layer_2"]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+        _LIB.orc_num_threads.restype = ctypes.c_int
+    return _LIB
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def _ptr_array(arrs):
+    keep = [_f32(a) for a in arrs]
+    arr = (ctypes.c_void_p * len(keep))(*[a.ctypes.data for a in keep])
+    return arr, keep
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+
+
+def mlp_weight_list(sd, prefix="fg_CD_predictor."):
+    out = []
+    for name in MLP_ORDER:
+        w = _np(sd[prefix + name + ".weight"])
+        out.append(w.reshape(w.shape[0], w.shape[1]))
+        out.append(_np(sd[prefix + name + ".bias"]))
+    return out
+
+
+def nr_weight_list(sd, n_blocks, prefix="neural_render."):
+    def wb(name):
+        w = _np(sd[prefix + name + ".weight"])
+        return [w.reshape(w.shape[0], w.shape[1]), _np(sd[prefix + name + ".bias"])]
+    out = wb("feat_2_rgb_list.0")
+    for i in range(n_blocks):
+        out += wb("feat_upsample_list.%d.layer_1" % i) + wb("feat_upsample_list.%d.layer_2" % i)
+        out += wb("feat_layers.%d" % i) + wb("feat_2_rgb_list.%d" % (i + 1))
+    return out
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(ctypes.c_int(int(n)))
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+def sample(xy, R, T, Kinv, n_samples, world_z1=2.5, world_z2=-3.5, t_rand=None):
+    xy, R, T, Kinv = _f32(xy), _f32(R), _f32(T).reshape(-1, 3), _f32(Kinv)
+    B, _, Nr = xy.shape
+    Ns = n_samples
+    tr = _f32(t_rand) if t_rand is not None else None
+    ray_d = np.empty((B, 3, Nr), np.float32)
+    ray_l = np.empty((B, 1, Nr), np.float32)
+    pts = np.empty((B, 3, Nr, Ns), np.float32)
+    zvals = np.empty((B, 1, Nr, Ns), np.float32)
+    z_dists = np.empty((B, 1, Nr, Ns), np.float32)
+    lib().orc_sample(B, Nr, Ns, _p(xy), _p(R), _p(T), _p(Kinv), ctypes.c_float(world_z1), ctypes.c_float(world_z2),
+                     _p(tr), _p(ray_d), _p(ray_l), _p(pts), _p(zvals), _p(z_dists))
+    return {"ray_d": ray_d, "ray_l": ray_l, "pts": pts, "zvals": zvals, "z_dists": z_dists}
+
+
+def embed(pts):
+    pts = _f32(pts)
+    B = pts.shape[0]
+    M = int(np.prod(pts.shape[2:]))
+    pe = np.empty((B, 63) + pts.shape[2:], np.float32)
+    lib().orc_embed(B, ctypes.c_long(M), _p(pts), _p(pe))
+    return pe
+
+
+def mlp(sd, pe, shape, appea, audio, C=256, H=384):
+    pe, shape, appea = _f32(pe), _f32(shape), _f32(appea)
+    audio = _f32(audio) if audio is not None and np.asarray(audio).size else None
+    B = pe.shape[0]
+    M = int(np.prod(pe.shape[2:]))
+    wl, keep = _ptr_array(mlp_weight_list(sd))
+    rgb = np.empty((B, C) + pe.shape[2:], np.float32)
+    dens = np.empty((B, 1) + pe.shape[2:], np.float32)
+    lib().orc_mlp(B, ctypes.c_long(M), H, C, shape.shape[1], appea.shape[1], 0 if audio is None else audio.shape[1], wl,
+                  _p(pe), _p(shape), _p(appea), _p(audio), _p(rgb), _p(dens))
+    return rgb, dens
+
+
+def composite(rgb, density, z_dists, zvals):
+    rgb, density, z_dists, zvals = _f32(rgb), _f32(density), _f32(z_dists), _f32(zvals)
+    B, C, Nr, Ns = rgb.shape
+    fg = np.empty((B, C, Nr), np.float32)
+    ba = np.empty((B, 1, Nr), np.float32)
+    dp = np.empty((B, 1, Nr), np.float32)
+    w = np.empty((B, 1, Nr, Ns), np.float32)
+    lib().orc_composite(B, Nr, Ns, C, _p(rgb), _p(density), _p(z_dists), _p(zvals), _p(fg), _p(ba), _p(dp), _p(w))
+    return fg, ba, dp, w
+
+
+def neural_render(sd, x, n_blocks, debug=False):
+    x = _f32(x)
+    B, C, fs, _ = x.shape
+    P = fs << n_blocks
+    wl, keep = _ptr_array(nr_weight_list(sd, n_blocks))
+    img = np.empty((B, 3, P, P), np.float32)
+    dbg = [None, None, None]
+    if debug:
+        c1 = max(C // 2, 32)
+        dbg = [np.empty((B, 3, 2 * fs, 2 * fs), np.float32), np.empty((B, C, 2 * fs, 2 * fs), np.float32),
+               np.empty((B, c1, 2 * fs, 2 * fs), np.float32)]
+    lib().orc_neural_render(B, C, fs, n_blocks, wl, _p(x), _p(img), _p(dbg[0]), _p(dbg[1]), _p(dbg[2]))
+    return (img, dbg) if debug else img
+
+
+def blur(x):
+    x = _f32(x)
+    B, C, h, w = x.shape
+    y = np.empty_like(x)
+    lib().orc_blur(B * C, h, w, _p(x), _p(y))
+    return y
+
+
+def forward(sd, opt, inp, t_rand=None, skip_neural_render=False):
+    """Whole path on the CPU.  inp: dict with the reference's kwarg names (numpy or torch)."""
+    import math
+    xy = _f32(_np(inp["batch_xy"]))
+    B, _, Nr = xy.shape
+    fs, C, H = opt.featmap_size, opt.featmap_nc, opt.mlp_hidden_nchannels
+    nb = int(math.log2(opt.pred_img_size) - math.log2(fs))
+    P = opt.pred_img_size
+    shape, appea = _f32(_np(inp["shape_code"])), _f32(_np(inp["appea_code"]))
+    audio = inp.get("audiostyle")
+    audio = _f32(_np(audio)) if audio is not None and _np(audio).size else None
+    mw, k1 = _ptr_array(mlp_weight_list(sd))
+    nw, k2 = _ptr_array(nr_weight_list(sd, nb))
+    bgf = _f32(_np(sd["neural_render.bg_featmap"]))
+    R, T, K = _f32(_np(inp["batch_Rmats"])), _f32(_np(inp["batch_Tvecs"])).reshape(-1, 3), _f32(_np(inp["batch_inv_inmats"]))
+    tr = _f32(_np(t_rand)) if t_rand is not None else None
+    fg = np.empty((B, C, Nr), np.float32)
+    ba = np.empty((B, 1, Nr), np.float32)
+    merge_img = np.empty((B, 3, P, P), np.float32)
+    bg_img = np.empty((1, 3, P, P), np.float32)
+    lib().orc_forward(B, Nr, opt.num_sample_coarse, fs, nb, H, C, shape.shape[1], appea.shape[1],
+                      0 if audio is None else audio.shape[1], mw, nw, _p(bgf), _p(xy), _p(R), _p(T), _p(K),
+                      ctypes.c_float(opt.world_z1), ctypes.c_float(opt.world_z2), _p(tr), _p(shape), _p(appea), _p(audio),
+                      _p(fg), _p(ba), _p(merge_img), _p(bg_img), int(skip_neural_render))
+    return {"fg_feat": fg, "bg_alpha": ba, "merge_img": merge_img, "bg_img": bg_img}

@@ -1,0 +1,131 @@
+"""The CPU restatement (oracle/) against golden vectors emitted by the reference itself.
+
+CPU-only.  Pins the oracle seam by seam before anything GPU-side trusts it.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, synthetic_case
+from oracle import oracle as orc
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["tiny_test", "tiny_train"])
+def test_sampler_and_embedder(name):
+    g, m = load_golden(name)
+    opt, sd, inp = synthetic_case(m)
+    t_rand = None
+    if m["mode"] == "train":
+        from n3dt import synthetic as syn
+        t_rand = t2n(syn.stratified_noise(m["batch"], opt.featmap_size ** 2, opt.num_sample_coarse, m["t_rand_seed"]))
+    s = orc.sample(t2n(inp["batch_xy"]), t2n(inp["batch_Rmats"]), t2n(inp["batch_Tvecs"]), t2n(inp["batch_inv_inmats"]),
+                   opt.num_sample_coarse, opt.world_z1, opt.world_z2, t_rand)
+    np.testing.assert_allclose(s["ray_d"], g["ray_d"], atol=2e-7)
+    np.testing.assert_allclose(s["ray_l"], g["ray_l"], rtol=3e-7)
+    np.testing.assert_allclose(s["pts"], g["pts"], atol=2e-6)
+    np.testing.assert_allclose(s["zvals"], g["zvals"], atol=2e-6)
+    np.testing.assert_allclose(s["z_dists"], g["z_dists"], atol=2e-6)
+    # PE from the golden points: isolates sin/cos accuracy from the 512x amplification of point error
+    pe = orc.embed(g["pts"])
+    np.testing.assert_allclose(pe, g["pe"], atol=1e-6)
+    # PE from our own points: the amplified bound (2^9 * point error)
+    pe2 = orc.embed(s["pts"])
+    np.testing.assert_allclose(pe2, g["pe"], atol=2e-3)
+
+
+def test_mlp_and_composite_seams():
+    g, m = load_golden("tiny_test")
+    opt, sd, inp = synthetic_case(m)
+    rgb, dens = orc.mlp(sd, g["pe"], t2n(inp["shape_code"]), t2n(inp["appea_code"]), t2n(inp["audiostyle"]))
+    np.testing.assert_allclose(dens, g["density"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(rgb, g["feat"], atol=2e-5, rtol=1e-4)
+    fg, ba, dp, w = orc.composite(g["feat"], g["density"], g["z_dists"], g["zvals"])
+    np.testing.assert_allclose(w, g["weight"], atol=1e-6)
+    np.testing.assert_allclose(fg, g["fg_feat"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(ba, g["bg_alpha"], atol=1e-6)
+    np.testing.assert_allclose(dp, g["depth"], atol=1e-5)
+
+
+def test_composite_saturation_edge():
+    """alpha -> 1 keeps the 1e-10 floor in the transmittance product."""
+    g, _ = load_golden("edges")
+    fg, ba, dp, w = orc.composite(g["sat.rgb"], g["sat.density"], g["sat.dists"], g["sat.zvals"])
+    np.testing.assert_allclose(w, g["sat.weight"], atol=1e-7, rtol=1e-5)
+    np.testing.assert_allclose(fg, g["sat.fg_feat"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(ba, g["sat.bg_alpha"], atol=1e-6)
+    # after the saturated sample the transmittance is 1e-10-ish, not 0
+    assert np.all(np.isfinite(w))
+
+
+def test_sampler_dz_zero_edge():
+    """A ray with d_z -> 0 gives inf/nan exactly where the reference does."""
+    g, _ = load_golden("edges")
+    s = orc.sample(g["dz0.xy"], g["dz0.R"], g["dz0.T"], g["dz0.Kinv"], 8)
+    ref_l = g["dz0.ray_l"]
+    assert np.array_equal(np.isfinite(s["ray_l"]), np.isfinite(ref_l))
+    fin = np.isfinite(ref_l)
+    np.testing.assert_allclose(s["ray_l"][fin], ref_l[fin], rtol=1e-5)
+    assert np.array_equal(np.isnan(s["pts"]), np.isnan(g["dz0.pts"]))
+
+
+def test_neural_render_seams():
+    g, m = load_golden("neural_render")
+    opt, sd, _ = synthetic_case(m)
+    np.testing.assert_allclose(orc.blur(g["blur_in"]), g["blur_out"], atol=1e-6)
+    img, dbg = orc.neural_render(sd, g["x"], 3, debug=True)
+    np.testing.assert_allclose(dbg[0], g["rgb0_up"], atol=2e-6)
+    np.testing.assert_allclose(dbg[1], g["psu0"], atol=2e-5)
+    np.testing.assert_allclose(dbg[2], g["net1"], atol=2e-5)
+    np.testing.assert_allclose(img, g["out"], atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["tiny_test", "tiny_train"])
+def test_forward_tiny(name):
+    g, m = load_golden(name)
+    opt, sd, inp = synthetic_case(m)
+    t_rand = None
+    if m["mode"] == "train":
+        from n3dt import synthetic as syn
+        t_rand = syn.stratified_noise(m["batch"], opt.featmap_size ** 2, opt.num_sample_coarse, m["t_rand_seed"])
+    out = orc.forward(sd, opt, inp, t_rand)
+    np.testing.assert_allclose(out["fg_feat"], g["fg_feat"], atol=2e-4)
+    np.testing.assert_allclose(out["bg_alpha"], g["bg_alpha"], atol=1e-4)
+    assert np.abs(out["merge_img"] - g["merge_img"]).max() <= 1e-3
+    assert np.abs(out["bg_img"] - g["bg_img"]).max() <= 1e-5
+
+
+def test_forward_variants():
+    """include_gaze (dim 64) and the audio-less *_yuan variant."""
+    g, m = load_golden("edges")
+    from n3dt import synthetic as syn
+    from conftest import options_from_manifest
+    opt = options_from_manifest(m)
+    sdg = syn.make_state_dict(opt, seed=3, include_gaze=True, eye_gaze_dim=64, bg_noise=0.1)
+    assert np.allclose(syn.state_dict_checksum(sdg), m["weights_checksum_gaze"], rtol=1e-9, atol=1e-6)
+    out = orc.forward(sdg, opt, syn.frame_inputs(opt, 1, include_gaze=True, eye_gaze_dim=64))
+    np.testing.assert_allclose(out["fg_feat"], g["gaze.fg_feat"], atol=2e-4)
+    assert np.abs(out["merge_img"] - g["gaze.merge_img"]).max() <= 1e-3
+    sdn = syn.make_state_dict(opt, seed=4, audio_dim=0, bg_noise=0.1)
+    assert np.allclose(syn.state_dict_checksum(sdn), m["weights_checksum_noaudio"], rtol=1e-9, atol=1e-6)
+    inpn = syn.frame_inputs(opt, 1, audio_dim=0)
+    inpn["audiostyle"] = None
+    out = orc.forward(sdn, opt, inpn)
+    np.testing.assert_allclose(out["fg_feat"], g["noaudio.fg_feat"], atol=2e-4)
+    assert np.abs(out["merge_img"] - g["noaudio.merge_img"]).max() <= 1e-3
+
+
+def test_forward_cfg1():
+    """BASELINE config 1 (fs 32, 32 samples, 256^2 image): full image within the 1e-3 gate."""
+    g, m = load_golden("cfg1")
+    opt, sd, inp = synthetic_case(m)
+    out = orc.forward(sd, opt, inp)
+    step = int(g["ray_index_step"])
+    np.testing.assert_allclose(out["fg_feat"][:, :, ::step], g["fg_feat"], atol=3e-4)
+    np.testing.assert_allclose(out["bg_alpha"], g["bg_alpha"], atol=1e-4)
+    ref = g["merge_img_q16"].astype(np.float32) / 65535.0
+    assert np.abs(out["merge_img"] - ref).max() <= 1e-3
+    refbg = g["bg_img_q16"].astype(np.float32) / 65535.0
+    assert np.abs(out["bg_img"] - refbg).max() <= 1e-4

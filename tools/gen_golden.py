@@ -1,0 +1,367 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container (it needs /root/reference).  It imports the
+reference's NetWorks package as-is, with one container-local stand-in for the
+un-vendored third-party call `kornia.filters.filter2d` (kornia==0.6.12,
+requirements.txt:61; call site NetWorks/PixelShuffleUpsample.py:18): documented
+semantics = cross-correlation with the kernel divided by sum(|k|), reflect
+border, same size.  The reference has no tests pinning that call, so the Blur
+seam is "parity unpinned" beyond this assumption (recorded in every manifest).
+
+Nothing of the reference travels: the fixtures hold inputs' seeds, small
+arrays of intermediate seams / outputs / sampled gradients, and a JSON manifest.
+Weights are NOT stored; they are regenerated from n3dt.synthetic.make_state_dict
+(seeded) and pinned by a checksum.
+
+Usage:  python tools/gen_golden.py [--only NAME ...]
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, os.path.join(REPO, "nerf-3dtalker-code_amd"))
+
+from n3dt import synthetic as syn  # noqa: E402
+from n3dt.options import BaseOptions  # noqa: E402
+
+
+def install_kornia_standin():
+    def filter2d(inp, kernel, border_type="reflect", normalized=False):
+        k = kernel
+        if normalized:
+            k = k / k.abs().sum(dim=(-2, -1), keepdim=True)
+        kh, kw = k.shape[-2:]
+        c = inp.shape[1]
+        w = k.expand(c, 1, kh, kw).to(inp)
+        x = F.pad(inp, [kw // 2, kw // 2, kh // 2, kh // 2], mode=border_type)
+        return F.conv2d(x, w, groups=c)
+
+    kornia = types.ModuleType("kornia")
+    filters = types.ModuleType("kornia.filters")
+    filters.filter2d = filter2d
+    kornia.filters = filters
+    sys.modules["kornia"] = kornia
+    sys.modules["kornia.filters"] = filters
+
+
+def import_reference():
+    install_kornia_standin()
+    sys.path.insert(0, REF)
+    from NetWorks.HeadNeRFNet import HeadNeRFNet  # noqa
+    from NetWorks.HeadNeRFNet_yuan import HeadNeRFNet as HeadNeRFNetNoAudio  # noqa
+    return HeadNeRFNet, HeadNeRFNetNoAudio
+
+
+def q16(img):
+    """[0,1] image -> uint16 (abs error 7.6e-6, far below the 1e-3 gate)."""
+    return np.round(np.clip(img, 0.0, 1.0) * 65535.0).astype(np.uint16)
+
+
+def np32(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def sample_grad(name, g, n=256):
+    """Full sum / abs-sum plus a fixed pseudo-random subset of a gradient."""
+    flat = g.detach().double().reshape(-1)
+    rng = np.random.RandomState(sum(map(ord, name)))
+    idx = np.sort(rng.choice(flat.numel(), size=min(n, flat.numel()), replace=False)).astype(np.int64)
+    return {
+        "sum": np.float64(flat.sum().item()),
+        "abs": np.float64(flat.abs().sum().item()),
+        "idx": idx,
+        "val": flat[torch.from_numpy(idx)].float().numpy(),
+    }
+
+
+def build_ref_net(HeadNeRFNet, opt, sd, include_gaze=False, eye_gaze_dim=2):
+    net = HeadNeRFNet(opt, include_vd=False, hier_sampling=False, include_gaze=include_gaze,
+                      eye_gaze_dim=eye_gaze_dim)
+    net.load_state_dict(sd, strict=True)  # proves the key inventory matches the reference
+    return net
+
+
+def run_seams(net, inp, mode, t_rand=None):
+    """Forward through the reference while recording every seam."""
+    seams = {}
+    orig_rand_like = torch.rand_like
+    if mode == "train":
+        def replay(z, *a, **k):
+            assert tuple(z.shape) == tuple(t_rand.shape), (z.shape, t_rand.shape)
+            return t_rand.to(z)
+        torch.rand_like = replay
+    try:
+        hooks = []
+
+        def rec(name):
+            def fn(_m, _i, out):
+                seams[name] = out
+            return fn
+        hooks.append(net.sample_func.register_forward_hook(rec("sample")))
+        hooks.append(net.vp_encoder.register_forward_hook(rec("pe")))
+        hooks.append(net.fg_CD_predictor.register_forward_hook(rec("mlp")))
+        hooks.append(net.calc_color_func.register_forward_hook(rec("color")))
+        nr_inputs = []
+        hooks.append(net.neural_render.register_forward_hook(
+            lambda _m, i, o: nr_inputs.append((i[0], o))))
+        kw = {k: inp[k] for k in ("bg_code", "shape_code", "appea_code", "batch_Rmats",
+                                   "batch_Tvecs", "batch_inv_inmats")}
+        if inp.get("audiostyle") is not None:
+            out = net(mode, inp["batch_xy"], inp["batch_uv"], inp["audiostyle"], **kw)
+        else:  # the *_yuan signature has no audio argument
+            out = net(mode, inp["batch_xy"], inp["batch_uv"], **kw)
+        for h in hooks:
+            h.remove()
+    finally:
+        torch.rand_like = orig_rand_like
+    seams["merge_featmap"] = nr_inputs[1][0]
+    return out["coarse_dict"], seams
+
+
+def losses(coarse, gt, mask, bg_value=1.0):
+    """The three MSE data terms (reference: Utils/HeadNeRFLossUtils.py:125-146,196-236);
+    restated here because that module needs torchvision/face_alignment to import."""
+    bg_img = coarse["bg_img"]
+    bg_loss = torch.mean((bg_img - bg_value) * (bg_img - bg_value))
+    res = torch.nan_to_num(coarse["merge_img"], nan=0.0)
+    head = (mask >= 0.5).expand(-1, 3, -1, -1)
+    nonhead = (mask < 0.5).expand(-1, 3, -1, -1)
+    head_loss = F.mse_loss(res[head], gt[head])
+    tv = res[nonhead] - bg_value
+    nonhead_loss = torch.mean(tv * tv)
+    return bg_loss, head_loss, nonhead_loss
+
+
+def disk_mask(batch, size):
+    yy, xx = torch.meshgrid(torch.arange(size), torch.arange(size), indexing="ij")
+    r2 = (xx - size / 2.0) ** 2 + (yy - size / 2.0) ** 2
+    m = (r2 <= (0.35 * size) ** 2).float()
+    return m.view(1, 1, size, size).repeat(batch, 1, 1, 1)
+
+
+def manifest_base(name, opt, extra):
+    m = {
+        "name": name,
+        "generator": "tools/gen_golden.py",
+        "reference": "NeRF-3DTalker NetWorks/* imported from /root/reference (torch %s, CPU)" % torch.__version__,
+        "blur_note": "kornia.filters.filter2d stand-in (correlation, kernel/sum|k|, reflect pad); Blur parity unpinned",
+        "featmap_size": opt.featmap_size, "featmap_nc": opt.featmap_nc,
+        "pred_img_size": opt.pred_img_size, "num_sample_coarse": opt.num_sample_coarse,
+    }
+    m.update(extra)
+    return m
+
+
+def save(name, arrays, manifest):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+# --------------------------------------------------------------------------------------
+def gen_tiny(HeadNeRFNet, mode):
+    """B=2, fs=8, N_s=8, pred 32: every seam + gradients of the trainer step."""
+    opt = BaseOptions({"featmap_size": 8, "featmap_nc": 256, "pred_img_size": 32, "num_sample_coarse": 8})
+    B = 2
+    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
+    net = build_ref_net(HeadNeRFNet, opt, sd)
+    inp = syn.frame_inputs(opt, B, yaw_range=0.3)
+    for k in ("audiostyle", "shape_code", "appea_code", "batch_Rmats", "batch_Tvecs"):
+        inp[k] = inp[k].clone().requires_grad_(True)
+    t_rand = syn.stratified_noise(B, opt.featmap_size ** 2, opt.num_sample_coarse) if mode == "train" else None
+    coarse, s = run_seams(net, inp, mode, t_rand)
+    gt = torch.full_like(coarse["merge_img"], 0.5)
+    mask = disk_mask(B, opt.pred_img_size)
+    bg_l, head_l, nonhead_l = losses(coarse, gt, mask)
+    total = bg_l + head_l + nonhead_l
+    total.backward()
+
+    samp = s["sample"]
+    arrays = {
+        "ray_d": np32(samp["batch_ray_d"].squeeze(-1)), "ray_l": np32(samp["batch_ray_l"].squeeze(-1)),
+        "pts": np32(samp["pts"]), "zvals": np32(samp["zvals"]), "z_dists": np32(samp["z_dists"]),
+        "pe": np32(s["pe"]), "feat": np32(s["mlp"][0]), "density": np32(s["mlp"][1]),
+        "fg_feat": np32(s["color"][0]), "bg_alpha": np32(s["color"][1]), "depth": np32(s["color"][2]),
+        "weight": np32(s["color"][3]), "merge_featmap": np32(s["merge_featmap"]),
+        "merge_img": np32(coarse["merge_img"]), "bg_img": np32(coarse["bg_img"]),
+        "loss_terms": np.array([bg_l.item(), head_l.item(), nonhead_l.item()], dtype=np.float64),
+    }
+    for k in ("audiostyle", "shape_code", "appea_code", "batch_Rmats", "batch_Tvecs"):
+        arrays["grad_in." + k] = np32(inp[k].grad)
+    for pname, p in net.named_parameters():
+        g = sample_grad(pname, p.grad)
+        for kk, vv in g.items():
+            arrays["grad_p.%s.%s" % (pname, kk)] = vv
+    # one Adam step on the net's parameters (reference: talker_trainer.py:722-723, lr 1e-4)
+    optim = torch.optim.Adam(net.parameters(), lr=1e-4)
+    optim.step()
+    for pname, p in net.named_parameters():
+        flat = p.detach().reshape(-1)
+        idx = torch.from_numpy(arrays["grad_p.%s.idx" % pname])
+        arrays["adam_p.%s.val" % pname] = flat[idx].numpy()
+    name = "tiny_" + mode
+    save(name, arrays, manifest_base(name, opt, {
+        "batch": B, "mode": mode, "weights_seed": 0, "bg_noise": 0.1, "yaw_range": 0.3,
+        "t_rand_seed": 7 if mode == "train" else None,
+        "weights_checksum": syn.state_dict_checksum(sd),
+        "loss": "bg+head+nonhead MSE, gt=0.5, disk mask r=0.35*size, bg_value=1",
+    }))
+
+
+def gen_cfg(HeadNeRFNet, name, fs, ns, pred, ray_step, B=1, crop=None):
+    opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": pred, "num_sample_coarse": ns})
+    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
+    net = build_ref_net(HeadNeRFNet, opt, sd)
+    inp = syn.frame_inputs(opt, B, yaw_range=0.3)
+    with torch.no_grad():
+        coarse, s = run_seams(net, inp, "test")
+    rays = slice(0, fs * fs, ray_step)
+    samp = s["sample"]
+    img = np32(coarse["merge_img"])
+    arrays = {
+        "ray_index_step": np.int64(ray_step),
+        "pts": np32(samp["pts"][:, :, rays]), "z_dists": np32(samp["z_dists"][:, :, rays]),
+        "density": np32(s["mlp"][1][:, :, rays]),
+        "feat_first8": np32(s["mlp"][0][:, :8, rays]),
+        "fg_feat": np32(s["color"][0][:, :, rays]), "bg_alpha": np32(s["color"][1]),
+        "depth": np32(s["color"][2]),
+        "merge_img_rowsum": img.astype(np.float64).sum(axis=-1),
+    }
+    bg = np32(coarse["bg_img"])
+    arrays["bg_img_rowsum"] = bg.astype(np.float64).sum(axis=-1)
+    if pred <= 256:
+        arrays["bg_img_q16"] = q16(bg)
+    else:
+        b0 = (pred - 128) // 2
+        arrays["bg_img_crop_q16"] = q16(bg[:, :, b0:b0 + 128, b0:b0 + 128])
+        arrays["bg_crop_origin"] = np.int64(b0)
+    if crop is None:
+        arrays["merge_img_q16"] = q16(img)
+    else:
+        c0 = (pred - crop) // 2
+        arrays["merge_img_crop_q16"] = q16(img[:, :, c0:c0 + crop, c0:c0 + crop])
+        arrays["crop_origin"] = np.int64(c0)
+    save(name, arrays, manifest_base(name, opt, {
+        "batch": B, "mode": "test", "weights_seed": 0, "bg_noise": 0.1, "yaw_range": 0.3,
+        "weights_checksum": syn.state_dict_checksum(sd),
+    }))
+
+
+def gen_edges(HeadNeRFNet, HeadNeRFNetNoAudio):
+    """Edge cases the path's arithmetic has and the two ctor variants."""
+    opt = BaseOptions({"featmap_size": 8, "featmap_nc": 256, "pred_img_size": 32, "num_sample_coarse": 8})
+    arrays = {}
+    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
+    net = build_ref_net(HeadNeRFNet, opt, sd)
+
+    # (1) alpha -> 1: huge density so that 1 - alpha + 1e-10 == 1e-10 exactly (Q6)
+    g = torch.Generator().manual_seed(5)
+    rgb = torch.randn(1, 256, 4, 8, generator=g)
+    dens = torch.rand(1, 1, 4, 8, generator=g) * 2.0
+    dens[0, 0, 0, 2] = 1.0e4
+    dens[0, 0, 1, 0] = 3.0e38
+    dens[0, 0, 2, :] = 0.0
+    dist = torch.full((1, 1, 4, 8), 0.75)
+    zv = torch.linspace(9.5, 15.5, 9)[:-1].view(1, 1, 1, 8).expand(1, 1, 4, 8).contiguous()
+    f, a, d, w = net.calc_color_func(None, rgb, dens, dist, zv)
+    arrays.update({"sat.rgb": np32(rgb), "sat.density": np32(dens), "sat.dists": np32(dist), "sat.zvals": np32(zv),
+                   "sat.fg_feat": np32(f), "sat.bg_alpha": np32(a), "sat.depth": np32(d), "sat.weight": np32(w)})
+
+    # (2) a camera whose optical axis lies in the z=const plane: d_z -> 0 for the centre ray (Q4)
+    xy, _ = syn.ray_grid(8)
+    R = torch.tensor([[[0.0, 0.0, 1.0], [0.0, -1.0, 0.0], [1.0, 0.0, 0.0]]])
+    T = torch.tensor([[[12.0], [0.0], [0.0]]])
+    Kinv = syn.inv_intrinsics(8, 1)
+    with torch.no_grad():
+        sdict = net.sample_func(xy, R, T, Kinv, False)
+    arrays.update({"dz0.R": np32(R), "dz0.T": np32(T), "dz0.Kinv": np32(Kinv), "dz0.xy": np32(xy),
+                   "dz0.ray_d": np32(sdict["batch_ray_d"].squeeze(-1)), "dz0.ray_l": np32(sdict["batch_ray_l"].squeeze(-1)),
+                   "dz0.pts": np32(sdict["pts"]), "dz0.z_dists": np32(sdict["z_dists"])})
+
+    # (3) include_gaze=True, eye_gaze_dim=64
+    sdg = syn.make_state_dict(opt, seed=3, include_gaze=True, eye_gaze_dim=64, bg_noise=0.1)
+    netg = build_ref_net(HeadNeRFNet, opt, sdg, include_gaze=True, eye_gaze_dim=64)
+    inpg = syn.frame_inputs(opt, 1, include_gaze=True, eye_gaze_dim=64)
+    with torch.no_grad():
+        cg, sg = run_seams(netg, inpg, "test")
+    arrays.update({"gaze.fg_feat": np32(sg["color"][0]), "gaze.bg_alpha": np32(sg["color"][1]),
+                   "gaze.merge_img": np32(cg["merge_img"])})
+
+    # (4) audio width 0: the *_yuan variant of the net (reference: NetWorks/models_yuan.py:32,62-68)
+    sdn = syn.make_state_dict(opt, seed=4, audio_dim=0, bg_noise=0.1)
+    netn = HeadNeRFNetNoAudio(opt, include_vd=False, hier_sampling=False)
+    netn.load_state_dict(sdn, strict=True)
+    inpn = syn.frame_inputs(opt, 1, audio_dim=0)
+    inpn["audiostyle"] = None
+    with torch.no_grad():
+        cn, sn = run_seams(netn, inpn, "test")
+    arrays.update({"noaudio.fg_feat": np32(sn["color"][0]), "noaudio.bg_alpha": np32(sn["color"][1]),
+                   "noaudio.merge_img": np32(cn["merge_img"])})
+
+    save("edges", arrays, manifest_base("edges", opt, {
+        "cases": ["sat (alpha->1, 1e-10 term)", "dz0 (d_z->0 ray)", "gaze (include_gaze, dim 64, seed 3)",
+                  "noaudio (audio width 0, seed 4)"],
+        "weights_checksum": syn.state_dict_checksum(sd),
+        "weights_checksum_gaze": syn.state_dict_checksum(sdg),
+        "weights_checksum_noaudio": syn.state_dict_checksum(sdn),
+    }))
+
+
+def gen_nr(HeadNeRFNet):
+    """Neural-renderer seams on a random feature map (stage outputs of 8a a8-a10)."""
+    opt = BaseOptions({"featmap_size": 8, "featmap_nc": 256, "pred_img_size": 64, "num_sample_coarse": 8})
+    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
+    net = build_ref_net(HeadNeRFNet, opt, sd)
+    nr = net.neural_render
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 256, 8, 8, generator=g)
+    arrays = {"x": np32(x)}
+    with torch.no_grad():
+        arrays["rgb0_up"] = np32(nr.rgb_upsample(nr.feat_2_rgb_list[0](x)))
+        psu0 = nr.feat_upsample_list[0](x)
+        arrays["psu0"] = np32(psu0)
+        net1 = nr.actvn(nr.feat_layers[0](psu0))
+        arrays["net1"] = np32(net1)
+        arrays["blur_in"] = np32(x[:, :4])
+        arrays["blur_out"] = np32(nr.feat_upsample_list[0].blur_layer(x[:, :4]))
+        arrays["out"] = np32(nr(x))
+    save("neural_render", arrays, manifest_base("neural_render", opt, {
+        "weights_seed": 0, "bg_noise": 0.1, "input_seed": 11, "weights_checksum": syn.state_dict_checksum(sd)}))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    HeadNeRFNet, HeadNeRFNetNoAudio = import_reference()
+    jobs = {
+        "tiny_test": lambda: gen_tiny(HeadNeRFNet, "test"),
+        "tiny_train": lambda: gen_tiny(HeadNeRFNet, "train"),
+        "edges": lambda: gen_edges(HeadNeRFNet, HeadNeRFNetNoAudio),
+        "neural_render": lambda: gen_nr(HeadNeRFNet),
+        "cfg1": lambda: gen_cfg(HeadNeRFNet, "cfg1", fs=32, ns=32, pred=256, ray_step=16),
+        "cfg2r": lambda: gen_cfg(HeadNeRFNet, "cfg2r", fs=64, ns=64, pred=512, ray_step=64),
+        "hr": lambda: gen_cfg(HeadNeRFNet, "hr", fs=32, ns=96, pred=1024, ray_step=16, crop=256),
+    }
+    for k, fn in jobs.items():
+        if args.only is None or k in args.only:
+            fn()
+
+
+if __name__ == "__main__":
+    main()
