@@ -1,0 +1,134 @@
+/*
+ * n3dt.h -- C ABI of libn3dt.so: the MI355X (gfx950) head-render hot path of NeRF-3DTalker.
+ *
+ * The reference has no FFI/operator seam for this path: the boundary is the Python module
+ * HeadNeRFNet (reference: NetWorks/HeadNeRFNet.py:10-207).  These entry points are what a
+ * binding for that module calls underneath; each one names the reference code it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch/ATen types.
+ *   - every data pointer is a DEVICE pointer (hipMalloc'd or torch-owned); all memory is
+ *     caller-owned, nothing is allocated or freed inside a call (hipGraph-capturable).
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); calls are
+ *     stream-ordered, asynchronous and re-entrant (no global mutable state).
+ *   - return 0 on success, a negative N3DT_E* code otherwise; never throws, never exits.
+ *     n3dt_last_error() returns a thread-local message for the last failing call.
+ *   - tensors are fp32 and contiguous unless a stride is given.  Feature maps cross this ABI
+ *     ray-major ("NHWC"): [B, N_r, C]; images are planar [B, 3, P, P] like the reference.
+ */
+#ifndef N3DT_API_H_
+#define N3DT_API_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define N3DT_ABI_VERSION 1
+
+/* arithmetic type of the MLP contraction */
+#define N3DT_F32 0  /* v_mfma_f32_16x16x4_f32, exact fp32: the <=1e-3 RGB parity mode */
+#define N3DT_BF16 1 /* v_mfma_f32_32x32x16_bf16, fp32 accumulate: the roofline mode  */
+#define N3DT_F16 2  /* v_mfma_f32_32x32x16_f16,  fp32 accumulate                      */
+
+#define N3DT_OK 0
+#define N3DT_EINVAL (-1)    /* bad geometry / null pointer / unsupported size */
+#define N3DT_EWORKSPACE (-2) /* workspace too small */
+#define N3DT_EHIP (-3)      /* a HIP runtime call failed */
+
+#define N3DT_PE_DIM 63      /* 3 + 6*10 (reference: NetWorks/HeadNeRFNet.py:27-28,50) */
+#define N3DT_MLP_LAYERS 12  /* FeaExt_module_0..7, density_module, RGB_layer_0..2 */
+
+/* Geometry of one call.  Mirrors what HeadNeRFNet reads from `opt` and from the input shapes
+ * (reference: NetWorks/HeadNeRFNet.py:22-45,131; HeadNeRFOptions.py:5-34). */
+typedef struct N3dtGeom {
+    int32_t batch;        /* B frames */
+    int32_t n_rays;       /* N_r rays per frame (featmap_size^2 for the reference reading) */
+    int32_t n_samples;    /* N_s = opt.num_sample_coarse */
+    int32_t hidden;       /* opt.mlp_hidden_nchannels; this build supports 384 */
+    int32_t feat_nc;      /* opt.featmap_nc (C); this build supports 256 */
+    int32_t shape_dim;    /* iden+expr(+gaze) code width, 179 (+eye_gaze_dim) */
+    int32_t appea_dim;    /* text+illu code width, 127 */
+    int32_t audio_dim;    /* 64, or 0 for the audio-less *_yuan variant */
+    int32_t featmap_size; /* fs; n_rays == fs*fs whenever the neural renderer follows */
+    int32_t n_blocks;     /* log2(pred_img_size / featmap_size) */
+    float world_z1;       /* opt.world_z1 (2.5)  */
+    float world_z2;       /* opt.world_z2 (-3.5) */
+    /* element strides of batch_xy [B,2,N_r]; the trainer passes an expand()ed view
+     * (reference: talker_trainer.py:768), so stride_b may be 0 */
+    int64_t xy_stride_b, xy_stride_c, xy_stride_r;
+} N3dtGeom;
+
+/* The MLP's fp32 parameters as PyTorch owns them: weight[l] is [out_l, in_l] row-major
+ * (Conv2d 1x1 weight viewed 2-D), bias[l] is [out_l]; order FeaExt_module_0..7, density_module,
+ * RGB_layer_0, RGB_layer_1, RGB_layer_2 (reference: NetWorks/models.py:29-59). */
+typedef struct N3dtMlpParams {
+    const float* weight[N3DT_MLP_LAYERS];
+    const float* bias[N3DT_MLP_LAYERS];
+} N3dtMlpParams;
+
+/* Neural-renderer parameters (reference: NetWorks/neural_renderer.py:49-69,
+ * NetWorks/PixelShuffleUpsample.py:29-33).  Index i = block, 0 <= i < n_blocks (<= 8). */
+#define N3DT_MAX_BLOCKS 8
+typedef struct N3dtRenderParams {
+    const float* to_rgb_w[N3DT_MAX_BLOCKS + 1]; /* feat_2_rgb_list.{0..n}: [3, c_i] */
+    const float* to_rgb_b[N3DT_MAX_BLOCKS + 1];
+    const float* psu1_w[N3DT_MAX_BLOCKS];       /* feat_upsample_list.i.layer_1: [2c, c]  */
+    const float* psu1_b[N3DT_MAX_BLOCKS];
+    const float* psu2_w[N3DT_MAX_BLOCKS];       /* feat_upsample_list.i.layer_2: [4c, 2c] */
+    const float* psu2_b[N3DT_MAX_BLOCKS];
+    const float* feat_w[N3DT_MAX_BLOCKS];       /* feat_layers.i: [c_{i+1}, c_i] */
+    const float* feat_b[N3DT_MAX_BLOCKS];
+} N3dtRenderParams;
+
+int n3dt_abi_version(void);
+const char* n3dt_last_error(void);
+
+/* ---- weights ------------------------------------------------------------------------------
+ * Re-lay the MLP weights into the MFMA-fragment order (and dtype) the fused kernel streams.
+ * PyTorch's optimizer mutates the fp32 parameters in place every step, so the binding
+ * re-packs whenever a parameter's version counter changed (SURVEY 8b "Parameters / ownership").
+ * Replaces: nothing in the reference (cuDNN consumes the Conv2d weights directly). */
+size_t n3dt_mlp_packed_bytes(const N3dtGeom* g, int precision);
+int n3dt_mlp_pack(const N3dtGeom* g, int precision, const N3dtMlpParams* p, void* packed, void* stream);
+
+/* ---- volumetric render: a1..a7 of SURVEY 8a in one call --------------------------------------
+ * Replaces, fused: GenSamplePoints.forward (NetWorks/utils.py:147-161), Embedder.forward
+ * (utils.py:43-51), the latent expand+concat (HeadNeRFNet.py:84,149-152), MLPforNeRF.forward
+ * (models.py:62-87), CalcRayColor.forward (utils.py:291-309) and the background merge
+ * (HeadNeRFNet.py:103-112).
+ *   xy      batch_xy, strides in g                R, Kinv [B,3,3]     T [B,3]
+ *   shape [B,shape_dim]  appea [B,appea_dim]  audio [B,audio_dim] (NULL iff audio_dim==0)
+ *   t_rand  [B,N_r,N_s+1] uniform noise for mode=="train" (utils.py:73-78), NULL for "test"
+ *   bg_featmap  neural_render.bg_featmap [C, N_r] (NCHW parameter), NULL to skip the merge
+ * outputs (any may be NULL except fg_feat):
+ *   fg_feat [B,N_r,C]  bg_alpha [B,N_r]  depth [B,N_r]  weight [B,N_r,N_s]
+ *   merge_feat [B,N_r,C] = fg_feat + bg_alpha * bg_featmap
+ * `saved` (nullable, n3dt_render_saved_bytes) receives what n3dt_render_bwd needs. */
+size_t n3dt_render_workspace_bytes(const N3dtGeom* g, int precision);
+int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, const N3dtMlpParams* p,
+                    const float* xy, const float* R, const float* T, const float* Kinv,
+                    const float* shape, const float* appea, const float* audio, const float* t_rand,
+                    const float* bg_featmap,
+                    float* fg_feat, float* bg_alpha, float* depth, float* weight, float* merge_feat,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- 2-D neural renderer: a8..a10 ----------------------------------------------------------------
+ * Replaces NeuralRenderer.forward (NetWorks/neural_renderer.py:72-91) including
+ * PixelShuffleUpsample.forward (PixelShuffleUpsample.py:36-45) and Blur (…:15-18, kornia filter2d).
+ *   featmap [nb, fs, fs, C] ray-major   ->   img [nb, 3, P, P], P = fs << n_blocks
+ * `nb` is the number of feature maps in this call (the binding renders the B merged maps and the
+ * background map together, nb = B+1; reference calls the module twice, HeadNeRFNet.py:109,113). */
+size_t n3dt_neural_render_workspace_bytes(const N3dtGeom* g, int nb);
+int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap, float* img,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* [C, N_r] (NCHW parameter) -> [N_r, C]; used to feed bg_featmap to the renderer */
+int n3dt_chw_to_hwc(int C, int n, const float* src, float* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* N3DT_API_H_ */

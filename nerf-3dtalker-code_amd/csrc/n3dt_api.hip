@@ -1,0 +1,150 @@
+// extern "C" entry points of libn3dt.so (declared in include/n3dt.h).
+// Host-side only: validates geometry, carves the caller's workspace and enqueues kernels on the
+// caller's stream.  No allocation, no synchronisation, no global mutable state.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/n3dt.h"
+#include "n3dt_layout.h"
+
+extern "C" {
+void n3dt_launch_pack(const N3dtGeom*, int, const N3dtMlpParams*, void*, hipStream_t);
+void n3dt_launch_fold(const N3dtGeom*, const N3dtMlpParams*, const float*, const float*, const float*, float*, hipStream_t);
+void n3dt_launch_ray_head(const N3dtGeom*, int, int, const float*, const float*, const float*, const float*, float*, float*,
+                          float*, float*, float*, hipStream_t);
+void n3dt_launch_chw_to_hwc(int, int, const float*, float*, hipStream_t);
+void n3dt_launch_nerf_fwd_f32(const N3dtGeom*, const N3dtMlpParams*, const void*, const float*, const float*, const float*,
+                              const float*, const float*, const float*, float*, float*, hipStream_t);
+void n3dt_launch_nerf_fwd_x16(const N3dtGeom*, int, const void*, const float*, const float*, const float*, const float*,
+                              const float*, const float*, float*, float*, hipStream_t);
+size_t n3dt_nr_workspace_floats(const N3dtGeom*, int);
+void n3dt_launch_neural_render(const N3dtGeom*, int, const N3dtRenderParams*, const float*, float*, float*, hipStream_t);
+}
+
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+static int check_hip(const char* where) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+        return N3DT_EHIP;
+    }
+    return N3DT_OK;
+}
+
+static int check_geom(const N3dtGeom* g, int precision) {
+    if (!g) return fail(N3DT_EINVAL, "geometry is NULL");
+    if (precision != N3DT_F32 && precision != N3DT_BF16 && precision != N3DT_F16) return fail(N3DT_EINVAL, "unknown precision");
+    if (g->batch < 1 || g->n_rays < 1 || g->n_samples < 1) return fail(N3DT_EINVAL, "batch, n_rays and n_samples must be >= 1");
+    if (g->n_samples > 1024) return fail(N3DT_EINVAL, "n_samples > 1024 is not supported");
+    if (g->hidden != 384) return fail(N3DT_EINVAL, "only mlp_hidden_nchannels == 384 is built");
+    if (g->feat_nc != 256) return fail(N3DT_EINVAL, "only featmap_nc == 256 is built");
+    if (g->shape_dim < 1 || g->appea_dim < 1 || g->audio_dim < 0) return fail(N3DT_EINVAL, "bad latent widths");
+    if (g->shape_dim + g->audio_dim > 512 || g->appea_dim > 512) return fail(N3DT_EINVAL, "latent width > 512");
+    return N3DT_OK;
+}
+
+static inline int block_samples(int precision) { return precision == N3DT_F32 ? 16 : 32; }
+static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct RenderCarve {
+    size_t fold, part, wlocal, total;  // byte offsets / total bytes
+    int bpr, bs;
+};
+
+static RenderCarve render_carve(const N3dtGeom* g, int precision) {
+    RenderCarve c;
+    c.bs = block_samples(precision);
+    c.bpr = (g->n_samples + c.bs - 1) / c.bs;
+    const size_t blocks = (size_t)g->batch * g->n_rays * c.bpr;
+    c.fold = 0;
+    c.part = align256((size_t)g->batch * N3DT_FOLD_STRIDE * sizeof(float));
+    c.wlocal = c.part + align256(blocks * (192 + 4) * sizeof(float));
+    c.total = c.wlocal + align256(blocks * c.bs * sizeof(float));
+    return c;
+}
+
+extern "C" int n3dt_abi_version(void) { return N3DT_ABI_VERSION; }
+extern "C" const char* n3dt_last_error(void) { return g_err; }
+
+extern "C" size_t n3dt_mlp_packed_bytes(const N3dtGeom* g, int precision) {
+    if (check_geom(g, precision) != N3DT_OK) return 0;
+    return n3dt_packed_tail_offset(precision) + n3dt_packed_tail_floats() * sizeof(float);
+}
+
+extern "C" int n3dt_mlp_pack(const N3dtGeom* g, int precision, const N3dtMlpParams* p, void* packed, void* stream) {
+    int rc = check_geom(g, precision);
+    if (rc) return rc;
+    if (!p || !packed) return fail(N3DT_EINVAL, "n3dt_mlp_pack: NULL argument");
+    for (int l = 0; l < N3DT_MLP_LAYERS; ++l)
+        if (!p->weight[l] || !p->bias[l]) return fail(N3DT_EINVAL, "n3dt_mlp_pack: NULL parameter pointer");
+    n3dt_launch_pack(g, precision, p, packed, (hipStream_t)stream);
+    return check_hip("n3dt_mlp_pack");
+}
+
+extern "C" size_t n3dt_render_workspace_bytes(const N3dtGeom* g, int precision) {
+    if (check_geom(g, precision) != N3DT_OK) return 0;
+    return render_carve(g, precision).total;
+}
+
+extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, const N3dtMlpParams* p, const float* xy,
+                               const float* R, const float* T, const float* Kinv, const float* shape, const float* appea,
+                               const float* audio, const float* t_rand, const float* bg_featmap, float* fg_feat,
+                               float* bg_alpha, float* depth, float* weight, float* merge_feat, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    int rc = check_geom(g, precision);
+    if (rc) return rc;
+    if (!packed_mlp || !p || !xy || !R || !T || !Kinv || !shape || !appea || !fg_feat || !workspace)
+        return fail(N3DT_EINVAL, "n3dt_render_fwd: NULL argument");
+    if (g->audio_dim > 0 && !audio) return fail(N3DT_EINVAL, "n3dt_render_fwd: audio is NULL but audio_dim > 0");
+    if (merge_feat && !bg_featmap) return fail(N3DT_EINVAL, "n3dt_render_fwd: merge_feat needs bg_featmap");
+    const RenderCarve c = render_carve(g, precision);
+    if (workspace_bytes < c.total) return fail(N3DT_EWORKSPACE, "n3dt_render_fwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)workspace;
+    float* fold = (float*)(ws + c.fold);
+    float* part = (float*)(ws + c.part);
+    float* wlocal = (float*)(ws + c.wlocal);
+    n3dt_launch_fold(g, p, shape, appea, audio, fold, s);
+    if (precision == N3DT_F32)
+        n3dt_launch_nerf_fwd_f32(g, p, packed_mlp, fold, xy, R, T, Kinv, t_rand, part, weight ? wlocal : nullptr, s);
+    else
+        n3dt_launch_nerf_fwd_x16(g, precision, packed_mlp, fold, xy, R, T, Kinv, t_rand, part, weight ? wlocal : nullptr, s);
+    const float* tail = (const float*)((const unsigned char*)packed_mlp + n3dt_packed_tail_offset(precision));
+    n3dt_launch_ray_head(g, c.bpr, c.bs, part, wlocal, tail, bg_featmap, fg_feat, bg_alpha, depth, weight, merge_feat, s);
+    return check_hip("n3dt_render_fwd");
+}
+
+extern "C" size_t n3dt_neural_render_workspace_bytes(const N3dtGeom* g, int nb) {
+    if (!g || nb < 1 || g->n_blocks < 1 || g->n_blocks > N3DT_MAX_BLOCKS || g->featmap_size < 2) return 0;
+    return n3dt_nr_workspace_floats(g, nb) * sizeof(float);
+}
+
+extern "C" int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap, float* img,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!g || !p || !featmap || !img || !workspace) return fail(N3DT_EINVAL, "n3dt_neural_render_fwd: NULL argument");
+    if (nb < 1) return fail(N3DT_EINVAL, "n3dt_neural_render_fwd: nb < 1");
+    if (g->n_blocks < 1 || g->n_blocks > N3DT_MAX_BLOCKS) return fail(N3DT_EINVAL, "n_blocks must be in 1..8");
+    if (g->feat_nc != 256) return fail(N3DT_EINVAL, "only featmap_nc == 256 is built");
+    if (g->featmap_size < 2) return fail(N3DT_EINVAL, "featmap_size < 2 (reflect border needs 2 pixels)");
+    if (workspace_bytes < n3dt_neural_render_workspace_bytes(g, nb)) return fail(N3DT_EWORKSPACE, "neural render workspace too small");
+    for (int i = 0; i <= g->n_blocks; ++i)
+        if (!p->to_rgb_w[i] || !p->to_rgb_b[i]) return fail(N3DT_EINVAL, "NULL feat_2_rgb parameter");
+    for (int i = 0; i < g->n_blocks; ++i)
+        if (!p->psu1_w[i] || !p->psu1_b[i] || !p->psu2_w[i] || !p->psu2_b[i] || !p->feat_w[i] || !p->feat_b[i])
+            return fail(N3DT_EINVAL, "NULL neural-render block parameter");
+    n3dt_launch_neural_render(g, nb, p, featmap, img, (float*)workspace, (hipStream_t)stream);
+    return check_hip("n3dt_neural_render_fwd");
+}
+
+extern "C" int n3dt_chw_to_hwc(int C, int n, const float* src, float* dst, void* stream) {
+    if (C < 1 || n < 1 || !src || !dst) return fail(N3DT_EINVAL, "n3dt_chw_to_hwc: bad argument");
+    n3dt_launch_chw_to_hwc(C, n, src, dst, (hipStream_t)stream);
+    return check_hip("n3dt_chw_to_hwc");
+}

@@ -1,0 +1,125 @@
+// Device-side helpers shared by the fused render kernels (gfx950 only).
+// Geometry follows the reference's fp32 operation order exactly (the library is built with
+// -ffp-contract=off); citations are into /root/reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/n3dt.h"
+
+#define N3DT_HID 384
+#define N3DT_C 256
+#define N3DT_G 192       // RGB_layer_1 width (hidden/2)
+#define N3DT_PE_ROWS 64  // 63 PE channels + one zero row
+#define N3DT_PART_STRIDE (N3DT_G + 4)  // per (ray, sample-block) partial: G[192], wsum, depth, Tprod, pad
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct N3dtFrameCam {  // per-frame camera, folded into scalars once per wave
+    float R[9], K[9], T[3];
+};
+
+// torch.linspace(0,1,steps) (CPU/CUDA kernels agree): symmetric evaluation around the midpoint.
+// Call site: NetWorks/utils.py:140.
+__device__ __forceinline__ float n3dt_linspace01(int i, int steps) {
+    float step = 1.0f / (float)(steps - 1);
+    int half = steps / 2;
+    return (i < half) ? step * (float)i : 1.0f - step * (float)(steps - 1 - i);
+}
+
+// GenSamplePoints.forward, NetWorks/utils.py:149-155: d = normalize(R (Kinv [x,y,1])), l = -1/d_z
+__device__ __forceinline__ void n3dt_ray_setup(const float* __restrict__ R, const float* __restrict__ K, float x, float y,
+                                               float d[3], float& l) {
+    float c[3], w[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c[i] = K[i * 3 + 0] * x + K[i * 3 + 1] * y + K[i * 3 + 2] * 1.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w[i] = R[i * 3 + 0] * c[0] + R[i * 3 + 1] * c[1] + R[i * 3 + 2] * c[2];
+    float n = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    d[0] = w[0] / n;
+    d[1] = w[1] / n;
+    d[2] = w[2] / n;
+    l = -1.0f / d[2];
+}
+
+// Edge j (0..Ns) of the sample planes; stratified jitter when tr != nullptr
+// (NetWorks/utils.py:142 and :73-78).
+__device__ __forceinline__ float n3dt_edge_z(float rz1, float rz2, int j, int Ns, const float* __restrict__ tr) {
+    float t = n3dt_linspace01(j, Ns + 1);
+    float zv = rz1 * (1.0f - t) + rz2 * t;
+    if (!tr) return zv;
+    float lower, upper;
+    if (j == 0) {
+        lower = zv;
+    } else {
+        float tp = n3dt_linspace01(j - 1, Ns + 1);
+        float zp = rz1 * (1.0f - tp) + rz2 * tp;
+        lower = 0.5f * (zv + zp);
+    }
+    if (j == Ns) {
+        upper = zv;
+    } else {
+        float tn = n3dt_linspace01(j + 1, Ns + 1);
+        float zn = rz1 * (1.0f - tn) + rz2 * tn;
+        upper = 0.5f * (zn + zv);
+    }
+    return lower + (upper - lower) * tr[j];
+}
+
+// One sample point of one ray: position, plane distance and z value (utils.py:80-86).
+// Lanes whose sample index is past N_s get a harmless point and dist = 0 (alpha = 0).
+__device__ __forceinline__ void n3dt_sample_point(const N3dtGeom& g, const float* __restrict__ xy, const float* __restrict__ R,
+                                                  const float* __restrict__ T, const float* __restrict__ Kinv,
+                                                  const float* __restrict__ t_rand, int b, int ray, int s, float p[3],
+                                                  float& dist, float& zval) {
+    const float* Rb = R + b * 9;
+    const float* Kb = Kinv + b * 9;
+    const float* Tb = T + b * 3;
+    float x = xy[(int64_t)b * g.xy_stride_b + 0 * g.xy_stride_c + (int64_t)ray * g.xy_stride_r];
+    float y = xy[(int64_t)b * g.xy_stride_b + 1 * g.xy_stride_c + (int64_t)ray * g.xy_stride_r];
+    float d[3], l;
+    n3dt_ray_setup(Rb, Kb, x, y, d, l);
+    float rz1 = Tb[2] - g.world_z1, rz2 = Tb[2] - g.world_z2;  // utils.py:125-126
+    const int Ns = g.n_samples;
+    if (s < Ns) {
+        const float* tr = t_rand ? t_rand + ((int64_t)b * g.n_rays + ray) * (Ns + 1) : nullptr;
+        float z_lo = n3dt_edge_z(rz1, rz2, s, Ns, tr);
+        float z_hi = n3dt_edge_z(rz1, rz2, s + 1, Ns, tr);
+        dist = (z_hi - z_lo) * l;
+        zval = z_lo;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) p[i] = Tb[i] + (d[i] * l) * z_lo;
+    } else {
+        dist = 0.0f;
+        zval = 0.0f;
+        p[0] = p[1] = p[2] = 0.0f;
+    }
+}
+
+// Positional-encoding channel `row` (0..63) of point p, accurate sin/cos (Embedder, utils.py:20-51):
+// [p, sin(2^0 p), cos(2^0 p), ..., sin(2^9 p), cos(2^9 p)], row 63 = 0 padding.
+__device__ __forceinline__ float n3dt_pe_row_accurate(const float p[3], int row) {
+    if (row < 3) return row == 0 ? p[0] : (row == 1 ? p[1] : p[2]);
+    if (row >= N3DT_PE_DIM) return 0.0f;
+    int k = (row - 3) / 6, w = (row - 3) % 6;
+    int dim = w % 3;
+    float v = dim == 0 ? p[0] : (dim == 1 ? p[1] : p[2]);
+    float a = v * (float)(1 << k);
+    return w < 3 ? sinf(a) : cosf(a);
+}
+
+// exclusive prefix product over `width` consecutive lanes (width 16 or 32, power of two)
+template <int WIDTH>
+__device__ __forceinline__ float n3dt_exclusive_prod(float x, int lane_in_group) {
+    float incl = x;
+#pragma unroll
+    for (int off = 1; off < WIDTH; off <<= 1) {
+        float o = __shfl_up(incl, off, WIDTH);
+        if (lane_in_group >= off) incl *= o;
+    }
+    float excl = __shfl_up(incl, 1, WIDTH);
+    return lane_in_group == 0 ? 1.0f : excl;
+}

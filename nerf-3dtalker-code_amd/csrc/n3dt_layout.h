@@ -1,0 +1,70 @@
+// Packed-weight layout shared by the pack kernels, the fused render kernels and the host API.
+//
+// The MLP is executed on "logical" layer matrices whose input-column order is the order of the
+// kernel's activation rows, with the per-frame latent columns removed (they are folded into a
+// per-frame bias, SURVEY section 6 footnote 1):
+//
+//   stage  logical [N x K]      source (reference: NetWorks/models.py:32-59)
+//   L0     384 x 64             FeaExt_module_0[:, 0:63] | zero column
+//   L1-4   384 x 384            FeaExt_module_1..4
+//   L5     384 x 448            FeaExt_module_5[:, 0:63] | zero | FeaExt_module_5[:, 63+S : 63+S+384]
+//   L6-7   384 x 384            FeaExt_module_6..7
+//   DEN    32 x 384             density_module (row 0), rows 1..31 zero
+//   RGB0   384 x 384            RGB_layer_0
+//   RGB1   192 x 384            RGB_layer_1[:, 0:384]
+//   RGB2   handled per ray after compositing (linear layer commutes with the weighted sum):
+//          stored transposed fp32 [192][256] + bias[256]
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#define N3DT_NSTAGE 11  // L0..L7, DEN, RGB0, RGB1
+
+struct N3dtStage {
+    int N, K;      // logical rows (padded), logical columns (padded)
+    int layer;     // index into N3dtMlpParams
+    int relu;
+};
+
+__host__ __device__ inline N3dtStage n3dt_stage(int s) {
+    switch (s) {
+        case 0: return {384, 64, 0, 1};
+        case 5: return {384, 448, 5, 1};
+        case 8: return {32, 384, 8, 1};
+        case 9: return {384, 384, 9, 0};
+        case 10: return {192, 384, 10, 1};
+        default: return {384, 384, s, 1};
+    }
+}
+
+// element offset of stage s inside the packed matrix region (elements, not bytes)
+__host__ __device__ inline size_t n3dt_stage_offset(int s) {
+    size_t off = 0;
+    for (int i = 0; i < s; ++i) {
+        N3dtStage st = n3dt_stage(i);
+        off += (size_t)st.N * st.K;
+    }
+    return off;
+}
+
+__host__ __device__ inline size_t n3dt_packed_matrix_elems() { return n3dt_stage_offset(N3DT_NSTAGE); }
+
+// the fp32 tail that follows the matrices in every precision: W2^T [192][256], b2 [256]
+__host__ __device__ inline size_t n3dt_packed_tail_floats() { return (size_t)192 * 256 + 256; }
+
+__host__ __device__ inline size_t n3dt_packed_elem_bytes(int precision) { return precision == 0 ? 4 : 2; }
+
+// byte offset of the fp32 tail (16-byte aligned)
+__host__ __device__ inline size_t n3dt_packed_tail_offset(int precision) {
+    size_t b = n3dt_packed_matrix_elems() * n3dt_packed_elem_bytes(precision);
+    return (b + 255) & ~(size_t)255;
+}
+
+// per-frame bias table in the workspace, [B][N3DT_FOLD_STRIDE], stage order:
+//   b0'[384] | b1..b4 [4x384] | b5'[384] | b6,b7 [2x384] | bden[32] (row 0 = density bias) | brgb0[384] | brgb1'[192]
+// b0', b5', brgb1' carry the folded latent codes of the frame; the others are plain copies so that
+// a wave reads every bias of its frame through one uniform (scalar-load) base pointer.
+#define N3DT_FOLD_STRIDE (384 * 10 + 32 + 192)
+__host__ __device__ inline int n3dt_bias_offset(int stage) {
+    return stage <= 8 ? 384 * stage : (stage == 9 ? 384 * 8 + 32 : 384 * 9 + 32);
+}

@@ -1,0 +1,240 @@
+// Small kernels around the fused render kernel: weight packing, per-frame latent folding and
+// the per-ray head (block combine + RGB_layer_2 + background merge).
+#include "n3dt_device.h"
+#include "n3dt_layout.h"
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing.  Logical matrices and their sources: n3dt_layout.h.
+// fp32 fragment order (v_mfma_f32_16x16x4_f32 A operand, 4 k-steps per 16-byte load):
+//   e = ((ot*(K/16) + k4)*64 + lane)*4 + j  ->  W'[ot*16 + (lane&15)][16*k4 + 4*j + (lane>>4)]
+// 16-bit fragment order (v_mfma_f32_32x32x16_{bf16,f16} A operand whose k order matches an
+// accumulator tile reused as the B operand, cdna guide section 3):
+//   e = ((ot*(K/16) + ks)*64 + lane)*8 + j  ->  W'[ot*32 + (lane&31)][32*(ks>>1) + 16*(ks&1) + 8*(j>>2) + 4*(lane>>5) + (j&3)]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float logical_weight(const N3dtMlpParams& p, int stage, int row, int col, int S, int A, int U) {
+    const int in0 = N3DT_PE_DIM + S + U, in5 = N3DT_PE_DIM + S + N3DT_HID, inr = N3DT_HID + A;
+    switch (stage) {
+        case 0: return col < N3DT_PE_DIM ? p.weight[0][(size_t)row * in0 + col] : 0.0f;
+        case 5:
+            if (col < N3DT_PE_DIM) return p.weight[5][(size_t)row * in5 + col];
+            if (col == N3DT_PE_DIM) return 0.0f;
+            return p.weight[5][(size_t)row * in5 + N3DT_PE_DIM + S + (col - 64)];
+        case 8: return row == 0 ? p.weight[8][col] : 0.0f;
+        case 10: return p.weight[10][(size_t)row * inr + col];
+        default: return p.weight[stage][(size_t)row * N3DT_HID + col];
+    }
+}
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+    __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+    return __builtin_bit_cast(unsigned short, h);
+}
+
+__global__ void pack_mlp_kernel(N3dtMlpParams p, int precision, int S, int A, int U, unsigned char* __restrict__ out) {
+    const int stage = blockIdx.y;
+    const N3dtStage st = n3dt_stage(stage);
+    const size_t n = (size_t)st.N * st.K;
+    const size_t base = n3dt_stage_offset(stage);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        int row, col;
+        if (precision == N3DT_F32) {
+            int j = e & 3, lane = (e >> 2) & 63;
+            size_t t = e >> 8;
+            int k4 = (int)(t % (st.K / 16)), ot = (int)(t / (st.K / 16));
+            row = ot * 16 + (lane & 15);
+            col = 16 * k4 + 4 * j + (lane >> 4);
+        } else {
+            int j = e & 7, lane = (e >> 3) & 63;
+            size_t t = e >> 9;
+            int ks = (int)(t % (st.K / 16)), ot = (int)(t / (st.K / 16));
+            row = ot * 32 + (lane & 31);
+            col = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+        }
+        float v = logical_weight(p, stage, row, col, S, A, U);
+        if (precision == N3DT_F32) {
+            reinterpret_cast<float*>(out)[base + e] = v;
+        } else if (precision == N3DT_BF16) {
+            reinterpret_cast<unsigned short*>(out)[base + e] = f32_to_bf16_rne(v);
+        } else {
+            _Float16 hv = (_Float16)v;
+            reinterpret_cast<unsigned short*>(out)[base + e] = __builtin_bit_cast(unsigned short, hv);
+        }
+    }
+}
+
+// W2^T [192][256] and b2 [256], fp32, after the matrices
+__global__ void pack_tail_kernel(N3dtMlpParams p, float* __restrict__ tail) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N3DT_G * N3DT_C) {
+        int j = i / N3DT_C, c = i % N3DT_C;
+        tail[i] = p.weight[11][(size_t)c * N3DT_G + j];
+    } else if (i < N3DT_G * N3DT_C + N3DT_C) {
+        tail[i] = p.bias[11][i - N3DT_G * N3DT_C];
+    }
+}
+
+extern "C" void n3dt_launch_pack(const N3dtGeom* g, int precision, const N3dtMlpParams* p, void* packed, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_mlp_kernel, dim3(64, N3DT_NSTAGE), dim3(256), 0, stream, *p, precision, g->shape_dim, g->appea_dim,
+                       g->audio_dim, reinterpret_cast<unsigned char*>(packed));
+    float* tail = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(packed) + n3dt_packed_tail_offset(precision));
+    const int n = N3DT_G * N3DT_C + N3DT_C;
+    hipLaunchKernelGGL(pack_tail_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, *p, tail);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-frame bias table (layout: n3dt_layout.h).  The shape / audio / appearance codes are constant
+// over a frame, so their weight columns collapse into a bias (replaces the expand+concat of
+// NetWorks/HeadNeRFNet.py:84,149-152 and models.py:69,80):
+//   b0'[o]  = b0[o]  + W0[o, 63:63+S].shape + W0[o, 63+S:].audio
+//   b5'[o]  = b5[o]  + W5[o, 63:63+S].shape
+//   br1'[o] = br1[o] + Wr1[o, 384:].appea
+// grid (B, N3DT_NSTAGE), block 384
+// ---------------------------------------------------------------------------------------------
+__global__ void fold_latents_kernel(N3dtMlpParams p, int S, int A, int U, const float* __restrict__ shape,
+                                    const float* __restrict__ appea, const float* __restrict__ audio, float* __restrict__ fold) {
+    const int b = blockIdx.x, stage = blockIdx.y, o = threadIdx.x;
+    __shared__ float code[512];
+    const int in0 = N3DT_PE_DIM + S + U, in5 = N3DT_PE_DIM + S + N3DT_HID, inr = N3DT_HID + A;
+    const int n_code = stage == 0 ? S + U : (stage == 5 ? S : (stage == 10 ? A : 0));
+    for (int i = threadIdx.x; i < n_code; i += blockDim.x) {
+        float v;
+        if (stage == 10) v = appea[(size_t)b * A + i];
+        else v = i < S ? shape[(size_t)b * S + i] : audio[(size_t)b * U + (i - S)];
+        code[i] = v;
+    }
+    __syncthreads();
+    const N3dtStage st = n3dt_stage(stage);
+    if (o >= st.N) return;
+    float* out = fold + (size_t)b * N3DT_FOLD_STRIDE + n3dt_bias_offset(stage);
+    if (stage == 8) {  // density: one real row
+        out[o] = o == 0 ? p.bias[8][0] : 0.0f;
+        return;
+    }
+    float acc = p.bias[st.layer][o];
+    const float* w = nullptr;
+    if (stage == 0) w = p.weight[0] + (size_t)o * in0 + N3DT_PE_DIM;
+    else if (stage == 5) w = p.weight[5] + (size_t)o * in5 + N3DT_PE_DIM;
+    else if (stage == 10) w = p.weight[10] + (size_t)o * inr + N3DT_HID;
+    for (int i = 0; i < n_code; ++i) acc = fmaf(w[i], code[i], acc);
+    out[o] = acc;
+}
+
+extern "C" void n3dt_launch_fold(const N3dtGeom* g, const N3dtMlpParams* p, const float* shape, const float* appea,
+                                 const float* audio, float* fold, hipStream_t stream) {
+    hipLaunchKernelGGL(fold_latents_kernel, dim3(g->batch, N3DT_NSTAGE), dim3(384), 0, stream, *p, g->shape_dim, g->appea_dim,
+                       g->audio_dim, shape, appea, audio, fold);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-ray head.  Combines the per-block partials front to back (the transmittance of a later
+// block is scaled by the product of the earlier blocks' (1 - alpha + 1e-10) factors: the same
+// cumprod as NetWorks/utils.py:283-287, re-associated), then applies RGB_layer_2 once per ray:
+//   fg[c] = sum_s w_s (W2 g_s + b2)[c] = W2[c,:] . (sum_s w_s g_s) + b2[c] * sum_s w_s
+// (models.py:82 is linear for featmap_nc != 3), and merges the learned background
+// (HeadNeRFNet.py:103-112): merge = fg + (1 - sum w) * bg_featmap.
+// 8 rays per 256-thread workgroup, thread = output channel.
+// ---------------------------------------------------------------------------------------------
+#define HEAD_RAYS 8
+#define HEAD_MAX_BPR 16
+__global__ __launch_bounds__(256) void ray_head_kernel(N3dtGeom g, int bpr, int bs, const float* __restrict__ part,
+                                                       const float* __restrict__ wlocal, const float* __restrict__ tail,
+                                                       const float* __restrict__ bg_featmap, float* __restrict__ fg_feat,
+                                                       float* __restrict__ bg_alpha, float* __restrict__ depth,
+                                                       float* __restrict__ weight, float* __restrict__ merge_feat) {
+    __shared__ float G[HEAD_RAYS][N3DT_G];
+    __shared__ float pref[HEAD_RAYS][HEAD_MAX_BPR];
+    __shared__ float wsum_s[HEAD_RAYS], dsum_s[HEAD_RAYS];
+    const long nrays_total = (long)g.batch * g.n_rays;
+    const long ray0 = (long)blockIdx.x * HEAD_RAYS;
+    const int t = threadIdx.x;
+    if (t < HEAD_RAYS) {
+        long rg = ray0 + t;
+        float Trun = 1.0f, ws = 0.0f, ds = 0.0f;
+        if (rg < nrays_total) {
+            for (int k = 0; k < bpr; ++k) {
+                const float* po = part + ((size_t)rg * bpr + k) * N3DT_PART_STRIDE + N3DT_G;
+                pref[t][k] = Trun;
+                ws += Trun * po[0];
+                ds += Trun * po[1];
+                Trun *= po[2];
+            }
+        }
+        wsum_s[t] = ws;
+        dsum_s[t] = ds;
+    }
+    __syncthreads();
+    for (int i = t; i < HEAD_RAYS * N3DT_G; i += 256) {
+        int r = i / N3DT_G, j = i % N3DT_G;
+        long rg = ray0 + r;
+        float acc = 0.0f;
+        if (rg < nrays_total)
+            for (int k = 0; k < bpr; ++k) acc += pref[r][k] * part[((size_t)rg * bpr + k) * N3DT_PART_STRIDE + j];
+        G[r][j] = acc;
+    }
+    __syncthreads();
+    const float* W2T = tail;
+    const float b2 = tail[N3DT_G * N3DT_C + t];
+    float acc[HEAD_RAYS];
+#pragma unroll
+    for (int r = 0; r < HEAD_RAYS; ++r) acc[r] = 0.0f;
+    for (int j = 0; j < N3DT_G; ++j) {
+        float wv = W2T[j * N3DT_C + t];
+#pragma unroll
+        for (int r = 0; r < HEAD_RAYS; ++r) acc[r] = fmaf(wv, G[r][j], acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < HEAD_RAYS; ++r) {
+        long rg = ray0 + r;
+        if (rg >= nrays_total) break;
+        float fg = acc[r] + b2 * wsum_s[r];
+        float ba = 1.0f - wsum_s[r];
+        fg_feat[(size_t)rg * N3DT_C + t] = fg;
+        if (merge_feat) {
+            int ray = (int)(rg % g.n_rays);
+            merge_feat[(size_t)rg * N3DT_C + t] = fg + ba * bg_featmap[(size_t)t * g.n_rays + ray];
+        }
+        if (t == 0) {
+            if (bg_alpha) bg_alpha[rg] = ba;
+            if (depth) depth[rg] = dsum_s[r];
+        }
+    }
+    if (weight) {
+        for (int i = t; i < HEAD_RAYS * g.n_samples; i += 256) {
+            int r = i / g.n_samples, s = i % g.n_samples;
+            long rg = ray0 + r;
+            if (rg < nrays_total) {
+                int k = s / bs;
+                weight[(size_t)rg * g.n_samples + s] = pref[r][k] * wlocal[((size_t)rg * bpr + k) * bs + (s % bs)];
+            }
+        }
+    }
+}
+
+extern "C" void n3dt_launch_ray_head(const N3dtGeom* g, int bpr, int bs, const float* part, const float* wlocal,
+                                     const float* tail, const float* bg_featmap, float* fg_feat, float* bg_alpha, float* depth,
+                                     float* weight, float* merge_feat, hipStream_t stream) {
+    const long nrays_total = (long)g->batch * g->n_rays;
+    const int grid = (int)((nrays_total + HEAD_RAYS - 1) / HEAD_RAYS);
+    hipLaunchKernelGGL(ray_head_kernel, dim3(grid), dim3(256), 0, stream, *g, bpr, bs, part, wlocal, tail,
+                       merge_feat ? bg_featmap : nullptr, fg_feat, bg_alpha, depth, weight, merge_feat);
+}
+
+// [C][n] -> [n][C]
+__global__ void chw_to_hwc_kernel(int C, int n, const float* __restrict__ src, float* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        int c = c0 + i, p = p0 + tx;
+        tile[i][tx] = (c < C && p < n) ? src[(size_t)c * n + p] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int p = p0 + i, c = c0 + tx;
+        if (c < C && p < n) dst[(size_t)p * C + c] = tile[tx][i];
+    }
+}
+
+extern "C" void n3dt_launch_chw_to_hwc(int C, int n, const float* src, float* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(chw_to_hwc_kernel, dim3((n + 31) / 32, (C + 31) / 32), dim3(256), 0, stream, C, n, src, dst);
+}

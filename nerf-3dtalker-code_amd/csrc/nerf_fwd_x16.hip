@@ -1,0 +1,333 @@
+// Fused volumetric-render kernel, 16-bit MFMA mode (bf16 or f16 inputs, fp32 accumulate):
+// the roofline path.
+//
+// One wavefront carries NB blocks of 32 consecutive samples of a ray (NB = 2 and N_s = 64: one
+// wavefront per ray) through the whole MLP with v_mfma_f32_32x32x16_{bf16,f16}.  Activations are
+// kept TRANSPOSED, H^T [channel][sample]: the sample sits on the MFMA column (lane & 31), the
+// channels in the accumulator registers.  A 32x32 accumulator tile, ReLU'd and packed to 16 bit,
+// is then directly the B operand of the next layer's MFMAs (its k order is a fixed permutation,
+// matched by the weight packing, cdna guide section 3), so activations never leave the register
+// file and LDS carries only weights.
+//
+// Weights: one flat stream of 1 KiB pieces (one MFMA A fragment each, lane-linear) in execution
+// order.  All waves of the workgroup consume the same stream; it is staged L2 -> LDS by LDS-DMA
+// (global_load_lds_dwordx4) in 24-piece chunks, double buffered, one workgroup barrier per chunk.
+// Every fragment read is a conflict-free lane-linear ds_read_b128.
+//
+// Epilogue per 32-sample block: density -> alpha -> in-block transmittance scan over the 32
+// lanes -> weights; the RGB_layer_1 activations are weighted and reduced over the samples with a
+// 5-step butterfly, so the only HBM traffic per block is one 196-float partial.
+#include "n3dt_device.h"
+#include "n3dt_layout.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define X16_BS 32
+#define X16_CH 24                      // pieces per chunk (24 KiB)
+#define X16_PIECE 1024                 // bytes
+#define X16_NCHUNK (2568 / X16_CH)     // 48 + 7*288 + 336 + 24 + 144 pieces
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+template <int PREC>
+struct X16;
+template <>
+struct X16<N3DT_BF16> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ frag pack(const float* v) {
+        frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (__bf16)v[j];
+        return f;
+    }
+    // ReLU on the packed 16-bit values: a signed 16-bit max with 0 (v_pk_max_i16) clears exactly
+    // the negative floats, and rounding commutes with it
+    static __device__ __forceinline__ frag relu(frag f) {
+        s16x8 s = __builtin_bit_cast(s16x8, f);
+        s = __builtin_elementwise_max(s, (s16x8)(0));
+        return __builtin_bit_cast(frag, s);
+    }
+};
+template <>
+struct X16<N3DT_F16> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ frag pack(const float* v) {
+        frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (_Float16)v[j];
+        return f;
+    }
+    static __device__ __forceinline__ frag relu(frag f) {
+        s16x8 s = __builtin_bit_cast(s16x8, f);
+        s = __builtin_elementwise_max(s, (s16x8)(0));
+        return __builtin_bit_cast(frag, s);
+    }
+};
+
+// The weight stream: chunk c lives in LDS buffer c&1 once advance() has returned for it.
+template <int WAVES>
+struct WeightStream {
+    const unsigned char* gsrc;  // per-lane: packed + (wave*PPW)*1KiB + lane*16
+    unsigned char* ring;        // LDS, 2 * X16_CH KiB
+    const unsigned char* cur;   // LDS buffer of the chunk being consumed (+ lane*16)
+    int chunk;                  // next chunk to hand out
+    int wave, lane;
+    static constexpr int PPW = X16_CH / WAVES;  // pieces each wave stages per chunk
+
+    __device__ __forceinline__ void issue(int c) {
+        const unsigned char* src = gsrc + (size_t)c * X16_CH * X16_PIECE;
+        unsigned char* dst = ring + (c & 1) * X16_CH * X16_PIECE + wave * PPW * X16_PIECE;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + i * X16_PIECE), (LDS_AS void*)(dst + i * X16_PIECE), 16, 0,
+                                             0);
+    }
+    __device__ __forceinline__ void advance() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk `chunk` have landed
+        __syncthreads();                                   // everyone's have; everyone is done with the other buffer
+        if (chunk + 1 < X16_NCHUNK) issue(chunk + 1);
+        cur = ring + (chunk & 1) * X16_CH * X16_PIECE + lane * 16;
+        ++chunk;
+    }
+};
+
+// positional-encoding channel `ch` (0..63) via v_sin_f32 on a two-term phase in revolutions
+__device__ __forceinline__ float pe_fast(const float p[3], const float rh[3], const float rl[3], int ch) {
+    if (ch < 3) return ch == 0 ? p[0] : (ch == 1 ? p[1] : p[2]);
+    if (ch >= N3DT_PE_DIM) return 0.0f;
+    const int k = (ch - 3) / 6, w = (ch - 3) % 6, dim = w % 3;
+    const float hi = dim == 0 ? rh[0] : (dim == 1 ? rh[1] : rh[2]);
+    const float lo = dim == 0 ? rl[0] : (dim == 1 ? rl[1] : rl[2]);
+    const float sc = (float)(1 << k);
+    float r = __builtin_amdgcn_fractf(hi * sc) + lo * sc + (w >= 3 ? 0.25f : 0.0f);  // cos x = sin(x + pi/2)
+    return __builtin_amdgcn_sinf(r);
+}
+
+enum { MODE_HIDDEN = 0, MODE_LINEAR = 1, MODE_DENSITY = 2, MODE_COMPOSITE = 3 };
+
+// sum over the 32 lanes of a half-wave of 32 per-lane values: lane c ends with value index rev5(c)
+__device__ __forceinline__ float butterfly32(float (&v)[32], const int c) {
+#pragma unroll
+    for (int step = 0; step < 5; ++step) {
+        const int m = 16 >> step;
+        const bool bit = (c & m) != 0;
+        const int n = 32 >> step;
+#pragma unroll
+        for (int i = 0; i < n / 2; ++i) {
+            float keep = bit ? v[2 * i + 1] : v[2 * i];
+            float send = bit ? v[2 * i] : v[2 * i + 1];
+            v[i] = keep + __shfl_xor(send, m, 64);
+        }
+    }
+    return v[0];
+}
+
+// One stage: out[N x 32*NB] = W'[N x K] . in[K x 32*NB] + bias (+ activation), NT = N/32 out tiles.
+// The KPE leading k-steps take their B operand from the wave's PE fragments: registers (pe_reg,
+// stage L0) or the wave's LDS copy (pe_lds, skip stage L5); the rest come from hin.
+// `bias` is wave-uniform, so the 32 values of a tile arrive by scalar loads; lane half h picks
+// rows (r&3)+8(r>>2)+4h of the tile.
+template <int PREC, int NB, int WAVES, int KS, int KPE, int NT, int MODE>
+__device__ __forceinline__ void x16_stage(WeightStream<WAVES>& ws, const float* __restrict__ bias,
+                                          const typename X16<PREC>::frag (&pe_reg)[NB][4], const unsigned char* pe_lds,
+                                          const typename X16<PREC>::frag (&hin)[NB][24], typename X16<PREC>::frag (&hout)[NB][24],
+                                          float (&aux)[NB], float* const (&po)[NB], const bool (&live)[NB], const int lane) {
+    typedef typename X16<PREC>::frag frag;
+    const int h = lane >> 5, c = lane & 31;
+    float red[NB][32];
+#pragma unroll
+    for (int ot = 0; ot < NT; ++ot) {
+        f32x16 acc[NB];
+        {
+            const float* bt = bias + ot * 32;
+            f32x16 binit;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row0 = (r & 3) + 8 * (r >> 2);
+                const float b0 = bt[row0], b1 = bt[row0 + 4];
+                binit[r] = h ? b1 : b0;
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = binit;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int p = ot * KS + ks;  // compile-time after unrolling
+            if (p % X16_CH == 0) ws.advance();
+            const frag a = *reinterpret_cast<const frag*>(ws.cur + (p % X16_CH) * X16_PIECE);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                frag b;
+                if (ks < KPE) {
+                    if (pe_lds) b = *reinterpret_cast<const frag*>(pe_lds + (nb * 4 + ks) * X16_PIECE);
+                    else b = pe_reg[nb][ks < 4 ? ks : 0];
+                } else {
+                    b = hin[nb][ks >= KPE ? ks - KPE : 0];
+                }
+                acc[nb] = X16<PREC>::mfma(a, b, acc[nb]);
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (MODE == MODE_HIDDEN || MODE == MODE_LINEAR) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[nb][r];
+                frag f0 = X16<PREC>::pack(v), f1 = X16<PREC>::pack(v + 8);
+                if (MODE == MODE_HIDDEN) {
+                    f0 = X16<PREC>::relu(f0);
+                    f1 = X16<PREC>::relu(f1);
+                }
+                hout[nb][2 * ot + 0] = f0;
+                hout[nb][2 * ot + 1] = f1;
+            } else if (MODE == MODE_DENSITY) {
+                aux[nb] = acc[nb][0];  // row 0 of the tile, valid on lanes with h == 0
+            } else {
+                // weighted RGB_layer_1 activations; two tiles (32 values) feed one butterfly over the samples
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[nb][(ot & 1) * 16 + r] = fmaxf(acc[nb][r], 0.0f) * aux[nb];
+                if (ot & 1) {
+                    float s = butterfly32(red[nb], c);
+                    // bit-reversed lane index = which of the 32 reduced values this lane ended up with
+                    const int v = ((c & 1) << 4) | ((c & 2) << 2) | (c & 4) | ((c & 8) >> 2) | ((c & 16) >> 4);
+                    const int reg = v & 15, tile = (ot - 1) + (v >> 4);
+                    if (live[nb]) po[nb][tile * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h] = s;
+                }
+            }
+        }
+    }
+}
+
+template <int PREC, int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 1) void nerf_fwd_x16_kernel(
+    N3dtGeom g, const unsigned char* __restrict__ packed, const float* __restrict__ fold, const float* __restrict__ xy,
+    const float* __restrict__ R, const float* __restrict__ T, const float* __restrict__ Kinv, const float* __restrict__ t_rand,
+    float* __restrict__ part, float* __restrict__ wlocal, int bpr, long total_blocks) {
+    typedef typename X16<PREC>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+
+    WeightStream<WAVES> ws;
+    ws.gsrc = packed + (size_t)wave * WeightStream<WAVES>::PPW * X16_PIECE + lane * 16;
+    ws.ring = lds;
+    ws.cur = lds;
+    ws.chunk = 0;
+    ws.wave = wave;
+    ws.lane = lane;
+    ws.issue(0);
+    // per-wave LDS copy of the PE fragments for the skip stage: NB*4 lane-linear 1 KiB pieces
+    unsigned char* pe_lds = lds + 2 * X16_CH * X16_PIECE + (size_t)wave * NB * 4 * X16_PIECE + lane * 16;
+
+    // block bookkeeping: the wave handles NB consecutive 32-sample blocks (all of one frame, host-checked)
+    bool live[NB];
+    float* po[NB];
+    long blk[NB];
+    float dist[NB], zval[NB];
+    frag pe[NB][4];
+    int frame = 0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        long bidx = ((long)blockIdx.x * WAVES + wave) * NB + nb;
+        live[nb] = bidx < total_blocks;
+        if (!live[nb]) bidx = total_blocks - 1;
+        blk[nb] = bidx;
+        po[nb] = part + (size_t)bidx * N3DT_PART_STRIDE;
+        const int sb = (int)(bidx % bpr);
+        const long rayg = bidx / bpr;
+        const int ray = (int)(rayg % g.n_rays);
+        const int b = (int)(rayg / g.n_rays);
+        if (nb == 0) frame = b;
+        float p[3];
+        n3dt_sample_point(g, xy, R, T, Kinv, t_rand, b, ray, sb * X16_BS + c, p, dist[nb], zval[nb]);
+        // phase in revolutions as hi + lo, so that the 2^k scaling of the encoder stays exact
+        float rh[3], rl[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float inv2pi_hi = 0.15915494f, inv2pi_lo = 6.2195e-09f;  // 1/(2 pi) split
+            rh[i] = p[i] * inv2pi_hi;
+            rl[i] = fmaf(p[i], inv2pi_hi, -rh[i]) + p[i] * inv2pi_lo;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = pe_fast(p, rh, rl, 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3));
+            pe[nb][ks] = X16<PREC>::pack(v);
+            *reinterpret_cast<frag*>(pe_lds + (nb * 4 + ks) * X16_PIECE) = pe[nb][ks];
+        }
+    }
+    const float* fb = fold + (size_t)__builtin_amdgcn_readfirstlane(frame) * N3DT_FOLD_STRIDE;
+
+    frag ha[NB][24], hb[NB][24];
+    float aux[NB];
+    // FeaExt_module_0..7 with the skip concat after layer 4 (reference: NetWorks/models.py:69-76)
+    x16_stage<PREC, NB, WAVES, 4, 4, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(0), pe, nullptr, ha, ha, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(1), pe, nullptr, ha, hb, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(2), pe, nullptr, hb, ha, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(3), pe, nullptr, ha, hb, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(4), pe, nullptr, hb, ha, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, 28, 4, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(5), pe, pe_lds, ha, hb, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(6), pe, nullptr, hb, ha, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(7), pe, nullptr, ha, hb, aux, po, live, lane);
+    // density head (models.py:78,84); the bias rides in the accumulator
+    x16_stage<PREC, NB, WAVES, 24, 0, 1, MODE_DENSITY>(ws, fb + n3dt_bias_offset(8), pe, nullptr, hb, ha, aux, po, live, lane);
+
+    // alpha, in-block transmittance and weights (reference: NetWorks/utils.py:273-289)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        float sp = __shfl(aux[nb], c, 64);  // row 0 lives on the h == 0 half
+        float sigma = fmaxf(sp, 0.0f);
+        float alpha = 1.0f - expf(-sigma * dist[nb]);
+        float x = 1.0f - alpha + 1e-10f;
+        float Tl = n3dt_exclusive_prod<32>(x, c);
+        float w = alpha * Tl;
+        float s0 = w, s1 = w * zval[nb];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            s0 += __shfl_xor(s0, off, 32);
+            s1 += __shfl_xor(s1, off, 32);
+        }
+        float tprod = __shfl(Tl * x, 31, 32);
+        if (live[nb] && lane == 0) {
+            po[nb][N3DT_G + 0] = s0;
+            po[nb][N3DT_G + 1] = s1;
+            po[nb][N3DT_G + 2] = tprod;
+            po[nb][N3DT_G + 3] = 0.0f;
+        }
+        if (live[nb] && wlocal && h == 0) wlocal[(size_t)blk[nb] * X16_BS + c] = w;
+        aux[nb] = w;
+    }
+    // feature head (models.py:79-82): RGB_layer_0 (linear), RGB_layer_1 (+appearance fold, relu),
+    // weighted by the sample weights and reduced over the block's samples
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_LINEAR>(ws, fb + n3dt_bias_offset(9), pe, nullptr, hb, ha, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, 24, 0, 6, MODE_COMPOSITE>(ws, fb + n3dt_bias_offset(10), pe, nullptr, ha, hb, aux, po, live, lane);
+}
+
+template <int PREC, int NB, int WAVES>
+static void launch_x16(const N3dtGeom* g, const void* packed, const float* fold, const float* xy, const float* R, const float* T,
+                       const float* Kinv, const float* t_rand, float* part, float* wlocal, hipStream_t stream) {
+    const int bpr = (g->n_samples + X16_BS - 1) / X16_BS;
+    const long total = (long)g->batch * g->n_rays * bpr;
+    const long per_wg = (long)WAVES * NB;
+    const int grid = (int)((total + per_wg - 1) / per_wg);
+    const size_t lds_bytes = 2 * X16_CH * X16_PIECE + (size_t)WAVES * NB * 4 * X16_PIECE;
+    auto kern = nerf_fwd_x16_kernel<PREC, NB, WAVES>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, *g, reinterpret_cast<const unsigned char*>(packed),
+                       fold, xy, R, T, Kinv, t_rand, part, wlocal, bpr, total);
+}
+
+extern "C" void n3dt_launch_nerf_fwd_x16(const N3dtGeom* g, int precision, const void* packed, const float* fold, const float* xy,
+                                         const float* R, const float* T, const float* Kinv, const float* t_rand, float* part,
+                                         float* wlocal, hipStream_t stream) {
+    if (precision == N3DT_BF16) launch_x16<N3DT_BF16, 1, 8>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, stream);
+    else launch_x16<N3DT_F16, 1, 8>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, stream);
+}

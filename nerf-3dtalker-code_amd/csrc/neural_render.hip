@@ -1,0 +1,254 @@
+// 2-D neural renderer (feature map -> RGB), fp32, ray-major ("NHWC") activations.
+//
+// Replaces (reference): NeuralRenderer.forward NetWorks/neural_renderer.py:72-91,
+// PixelShuffleUpsample.forward NetWorks/PixelShuffleUpsample.py:36-45, Blur :15-18
+// (kornia.filters.filter2d: depthwise [1,2,1]x[1,2,1]/16, reflect border) and
+// nn.Upsample(scale_factor=2, bilinear, align_corners=False) :54-55.
+//
+// Every 1x1 convolution is a pixel-major GEMM  Y[pix][o] = X[pix][:] . W[o][:] + b[o]  on
+// v_mfma_f32_32x32x2_f32 (exact fp32); pixel-shuffle is a store-address permutation in the
+// second PSU GEMM's epilogue; the RGB skip pyramid stays planar [nb,3,h,w] like the output.
+#include "n3dt_device.h"
+
+#define EPI_LRELU 0   // Y = lrelu(acc + b)
+#define EPI_PSU 1     // Y(pixel-shuffled) = lrelu(acc + b) + X.repeat(1,4,1,1)
+
+struct GemmEpi {
+    float* y;          // output
+    const float* res;  // EPI_PSU: the block input X [M][C]
+    int C;             // EPI_PSU: input channels (N == 4C)
+    int H, W;          // EPI_PSU: input resolution (M == nb*H*W)
+    float slope;       // leaky-relu slope, <0 = identity
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ X,
+                                                       const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                       GemmEpi ea) {
+    __shared__ float As[16][68];
+    __shared__ float Bs[16][68];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int lrow = tid >> 2, kq = tid & 3;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + lrow < M) a = *reinterpret_cast<const f32x4*>(X + (size_t)(m0 + lrow) * K + k0 + 4 * kq);
+        if (n0 + lrow < N) b = *reinterpret_cast<const f32x4*>(Wt + (size_t)(n0 + lrow) * K + k0 + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            As[4 * kq + j][lrow] = a[j];
+            Bs[4 * kq + j][lrow] = b[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            float av = As[kk + (lane >> 5)][wr * 32 + (lane & 31)];
+            float bv = Bs[kk + (lane >> 5)][wc * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int n = n0 + wc * 32 + (lane & 31);
+    if (n >= N) return;
+    const float bn = bias[n];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (m >= M) continue;
+        float v = acc[reg] + bn;
+        if (ea.slope >= 0.0f) v = v > 0.0f ? v : v * ea.slope;
+        if (EPI == EPI_LRELU) {
+            ea.y[(size_t)m * N + n] = v;
+        } else {
+            // out + x.repeat(1,4,1,1) then pixel_shuffle(2): out[c, 2h+i, 2w+j] = in[4c+2i+j, h, w]
+            v += ea.res[(size_t)m * ea.C + (n % ea.C)];
+            const int c = n >> 2, di = (n >> 1) & 1, dj = n & 1;
+            const int w = m % ea.W, h = (m / ea.W) % ea.H, img = m / (ea.W * ea.H);
+            ea.y[(((size_t)img * 2 * ea.H + 2 * h + di) * 2 * ea.W + 2 * w + dj) * ea.C + c] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// Blur on [nb,H,W,C]: one thread = one pixel x 4 channels
+__global__ void blur_nhwc_kernel(int nb, int H, int W, int C, const float* __restrict__ x, float* __restrict__ y) {
+    const int c4 = C / 4;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)nb * H * W * c4;
+    if (i >= total) return;
+    int cq = (int)(i % c4);
+    size_t pix = i / c4;
+    int w = (int)(pix % W), h = (int)((pix / W) % H), img = (int)(pix / ((size_t)W * H));
+    const float k[3] = {0.25f, 0.5f, 0.25f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int di = -1; di <= 1; ++di)
+#pragma unroll
+        for (int dj = -1; dj <= 1; ++dj) {
+            int hh = reflect1(h + di, H), ww = reflect1(w + dj, W);
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)img * H + hh) * W + ww) * C + 4 * cq);
+            float kw = k[di + 1] * k[dj + 1];
+            acc += kw * v;
+        }
+    *reinterpret_cast<f32x4*>(y + pix * C + 4 * cq) = acc;
+}
+
+// feat_2_rgb: net [nb*H*W][K] -> planar rgb [nb,3,H,W]; optional accumulate and final sigmoid
+__global__ void to_rgb_kernel(int nb, int HW, int K, const float* __restrict__ net, const float* __restrict__ Wt,
+                              const float* __restrict__ bias, const float* __restrict__ rgb_in, float* __restrict__ rgb_out,
+                              int final_sigmoid) {
+    extern __shared__ float wl[];  // [3][K]
+    for (int i = threadIdx.x; i < 3 * K; i += blockDim.x) wl[i] = Wt[i];
+    __syncthreads();
+    size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (size_t)nb * HW) return;
+    const float* xr = net + pix * K;
+    float a0 = bias[0], a1 = bias[1], a2 = bias[2];
+    for (int k = 0; k < K; k += 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a0 = fmaf(wl[k + j], v[j], a0);
+            a1 = fmaf(wl[K + k + j], v[j], a1);
+            a2 = fmaf(wl[2 * K + k + j], v[j], a2);
+        }
+    }
+    size_t img = pix / HW, p = pix % HW;
+    size_t o = img * 3 * (size_t)HW + p;
+    if (rgb_in) {
+        a0 = rgb_in[o] + a0;
+        a1 = rgb_in[o + HW] + a1;
+        a2 = rgb_in[o + 2 * (size_t)HW] + a2;
+    }
+    if (final_sigmoid) {
+        a0 = 1.0f / (1.0f + expf(-a0));
+        a1 = 1.0f / (1.0f + expf(-a1));
+        a2 = 1.0f / (1.0f + expf(-a2));
+    }
+    rgb_out[o] = a0;
+    rgb_out[o + HW] = a1;
+    rgb_out[o + 2 * (size_t)HW] = a2;
+}
+
+__device__ __forceinline__ float bilinear_at(const float* __restrict__ x, int h, int w, int i, int j) {
+    // value of the 2x bilinear upsample (align_corners=False) of x[h][w] at output pixel (i, j)
+    float si = fmaxf(0.5f * ((float)i + 0.5f) - 0.5f, 0.0f);
+    float sj = fmaxf(0.5f * ((float)j + 0.5f) - 0.5f, 0.0f);
+    int i0 = (int)si, j0 = (int)sj;
+    int i1 = i0 + (i0 < h - 1 ? 1 : 0), j1 = j0 + (j0 < w - 1 ? 1 : 0);
+    float li = si - (float)i0, lj = sj - (float)j0;
+    return (1.0f - li) * ((1.0f - lj) * x[i0 * w + j0] + lj * x[i0 * w + j1]) +
+           li * ((1.0f - lj) * x[i1 * w + j0] + lj * x[i1 * w + j1]);
+}
+
+// rgb_upsample = bilinear x2 then Blur, planar [n_planes][h][w] -> [n_planes][2h][2w]
+__global__ void rgb_up_kernel(int n_planes, int h, int w, const float* __restrict__ x, float* __restrict__ y) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int H2 = 2 * h, W2 = 2 * w;
+    if (i >= (size_t)n_planes * H2 * W2) return;
+    int oj = (int)(i % W2), oi = (int)((i / W2) % H2);
+    size_t pl = i / ((size_t)W2 * H2);
+    const float* xp = x + pl * (size_t)h * w;
+    const float k[3] = {0.25f, 0.5f, 0.25f};
+    float acc = 0.0f;
+#pragma unroll
+    for (int di = -1; di <= 1; ++di)
+#pragma unroll
+        for (int dj = -1; dj <= 1; ++dj)
+            acc += (k[di + 1] * k[dj + 1]) * bilinear_at(xp, h, w, reflect1(oi + di, H2), reflect1(oj + dj, W2));
+    y[i] = acc;
+}
+
+static inline int nr_ch(int C, int i) {
+    int v = C >> i;
+    return v < 32 ? 32 : v;
+}
+
+static void launch_gemm(int epi, int M, int N, int K, const float* X, const float* Wt, const float* b, GemmEpi ea,
+                        hipStream_t s) {
+    dim3 grid((M + 63) / 64, (N + 63) / 64);
+    if (epi == EPI_LRELU) hipLaunchKernelGGL(gemm_f32_kernel<EPI_LRELU>, grid, dim3(256), 0, s, M, N, K, X, Wt, b, ea);
+    else hipLaunchKernelGGL(gemm_f32_kernel<EPI_PSU>, grid, dim3(256), 0, s, M, N, K, X, Wt, b, ea);
+}
+
+// workspace carve (floats): t1 | ps | bl | netA | netB | rgbA | rgbB
+struct NrCarve {
+    size_t t1, ps, bl, net, rgb, total;
+};
+
+static NrCarve nr_carve(const N3dtGeom* g, int nb) {
+    NrCarve c = {0, 0, 0, 0, 0, 0};
+    const int C = g->feat_nc;
+    for (int i = 0; i < g->n_blocks; ++i) {
+        size_t h = (size_t)g->featmap_size << i, M = (size_t)nb * h * h;
+        size_t ci = nr_ch(C, i), co = nr_ch(C, i + 1);
+        if (M * 2 * ci > c.t1) c.t1 = M * 2 * ci;
+        if (4 * M * ci > c.ps) c.ps = 4 * M * ci;
+        if (4 * M * co > c.net) c.net = 4 * M * co;
+    }
+    c.bl = c.ps;
+    size_t P = (size_t)g->featmap_size << g->n_blocks;
+    c.rgb = (size_t)nb * 3 * P * P;
+    c.total = c.t1 + c.ps + c.bl + 2 * c.net + 2 * c.rgb;
+    return c;
+}
+
+extern "C" size_t n3dt_nr_workspace_floats(const N3dtGeom* g, int nb) { return nr_carve(g, nb).total; }
+
+extern "C" void n3dt_launch_neural_render(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap,
+                                          float* img, float* ws, hipStream_t s) {
+    const NrCarve cv = nr_carve(g, nb);
+    float* t1 = ws;
+    float* ps = t1 + cv.t1;
+    float* bl = ps + cv.ps;
+    float* netA = bl + cv.bl;
+    float* netB = netA + cv.net;
+    float* rgbA = netB + cv.net;
+    float* rgbB = rgbA + cv.rgb;
+    const int C = g->feat_nc, fs = g->featmap_size, nblk = g->n_blocks;
+    int h = fs;
+    // rgb = rgb_upsample(feat_2_rgb_list[0](x))   (neural_renderer.py:75)
+    {
+        size_t npix = (size_t)nb * h * h;
+        hipLaunchKernelGGL(to_rgb_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 3 * C * sizeof(float), s, nb, h * h, C,
+                           featmap, p->to_rgb_w[0], p->to_rgb_b[0], (const float*)nullptr, rgbB, 0);
+        size_t nout = (size_t)nb * 3 * 4 * h * h;
+        hipLaunchKernelGGL(rgb_up_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, nb * 3, h, h, rgbB, rgbA);
+    }
+    const float* net = featmap;
+    float* cur = netA;
+    float* oth = netB;
+    for (int i = 0; i < nblk; ++i) {
+        const int ci = nr_ch(C, i), co = nr_ch(C, i + 1);
+        const int M = nb * h * h;
+        GemmEpi e1 = {t1, nullptr, 0, 0, 0, 0.2f};
+        launch_gemm(EPI_LRELU, M, 2 * ci, ci, net, p->psu1_w[i], p->psu1_b[i], e1, s);
+        GemmEpi e2 = {ps, net, ci, h, h, 0.2f};
+        launch_gemm(EPI_PSU, M, 4 * ci, 2 * ci, t1, p->psu2_w[i], p->psu2_b[i], e2, s);
+        h *= 2;
+        {
+            size_t n = (size_t)nb * h * h * (ci / 4);
+            hipLaunchKernelGGL(blur_nhwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nb, h, h, ci, ps, bl);
+        }
+        GemmEpi e3 = {cur, nullptr, 0, 0, 0, 0.2f};
+        launch_gemm(EPI_LRELU, nb * h * h, co, ci, bl, p->feat_w[i], p->feat_b[i], e3, s);
+        const bool last = (i == nblk - 1);
+        size_t npix = (size_t)nb * h * h;
+        // rgb = rgb + feat_2_rgb_list[i+1](net); sigmoid after the last block (neural_renderer.py:82-88)
+        hipLaunchKernelGGL(to_rgb_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 3 * co * sizeof(float), s, nb, h * h, co,
+                           cur, p->to_rgb_w[i + 1], p->to_rgb_b[i + 1], (const float*)rgbA, last ? img : rgbB, last ? 1 : 0);
+        if (!last) {
+            size_t nout = (size_t)nb * 3 * 4 * h * h;
+            hipLaunchKernelGGL(rgb_up_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, nb * 3, h, h, rgbB, rgbA);
+        }
+        net = cur;
+        float* t = cur;
+        cur = oth;
+        oth = t;
+    }
+}

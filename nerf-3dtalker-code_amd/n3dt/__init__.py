@@ -1,0 +1,3 @@
+"""n3dt: MI355X-native volumetric head rendering behind NeRF-3DTalker's HeadNeRFNet interface."""
+from .options import BaseOptions  # noqa: F401
+from .headnerf import HeadNeRFNet, NeuralRenderer, MLPforNeRF  # noqa: F401

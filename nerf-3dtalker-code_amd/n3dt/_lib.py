@@ -1,0 +1,90 @@
+"""ctypes binding of libn3dt.so (C ABI: include/n3dt.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, importing
+this module's `lib()` raises.  Build it with `make -C nerf-3dtalker-code_amd` (or
+`python -c "import __graft_entry__ as g; g.build()"`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libn3dt.so")
+
+F32, BF16, F16 = 0, 1, 2
+PRECISIONS = {"fp32": F32, "f32": F32, "bf16": BF16, "fp16": F16, "f16": F16}
+MLP_LAYERS = 12
+MAX_BLOCKS = 8
+
+MLP_ORDER = ["FeaExt_module_%d" % i for i in range(8)] + ["density_module", "RGB_layer_0", "RGB_layer_1", "RGB_layer_2"]
+
+
+class Geom(ctypes.Structure):
+    _fields_ = [
+        ("batch", ctypes.c_int32), ("n_rays", ctypes.c_int32), ("n_samples", ctypes.c_int32),
+        ("hidden", ctypes.c_int32), ("feat_nc", ctypes.c_int32), ("shape_dim", ctypes.c_int32),
+        ("appea_dim", ctypes.c_int32), ("audio_dim", ctypes.c_int32), ("featmap_size", ctypes.c_int32),
+        ("n_blocks", ctypes.c_int32), ("world_z1", ctypes.c_float), ("world_z2", ctypes.c_float),
+        ("xy_stride_b", ctypes.c_int64), ("xy_stride_c", ctypes.c_int64), ("xy_stride_r", ctypes.c_int64),
+    ]
+
+
+class MlpParams(ctypes.Structure):
+    _fields_ = [("weight", ctypes.c_void_p * MLP_LAYERS), ("bias", ctypes.c_void_p * MLP_LAYERS)]
+
+
+class RenderParams(ctypes.Structure):
+    _fields_ = [
+        ("to_rgb_w", ctypes.c_void_p * (MAX_BLOCKS + 1)), ("to_rgb_b", ctypes.c_void_p * (MAX_BLOCKS + 1)),
+        ("psu1_w", ctypes.c_void_p * MAX_BLOCKS), ("psu1_b", ctypes.c_void_p * MAX_BLOCKS),
+        ("psu2_w", ctypes.c_void_p * MAX_BLOCKS), ("psu2_b", ctypes.c_void_p * MAX_BLOCKS),
+        ("feat_w", ctypes.c_void_p * MAX_BLOCKS), ("feat_b", ctypes.c_void_p * MAX_BLOCKS),
+    ]
+
+
+EXPORTS = [
+    "n3dt_abi_version", "n3dt_last_error", "n3dt_mlp_packed_bytes", "n3dt_mlp_pack",
+    "n3dt_render_workspace_bytes", "n3dt_render_fwd", "n3dt_neural_render_workspace_bytes",
+    "n3dt_neural_render_fwd", "n3dt_chw_to_hwc",
+]
+
+_LIB = None
+
+
+class N3dtError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise N3dtError("libn3dt.so not found at %s -- the HIP extension is required (no CPU fallback); "
+                        "run `make -C nerf-3dtalker-code_amd`" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    L.n3dt_abi_version.restype = ci
+    L.n3dt_last_error.restype = ctypes.c_char_p
+    L.n3dt_mlp_packed_bytes.restype = sz
+    L.n3dt_mlp_packed_bytes.argtypes = [ctypes.POINTER(Geom), ci]
+    L.n3dt_mlp_pack.restype = ci
+    L.n3dt_mlp_pack.argtypes = [ctypes.POINTER(Geom), ci, ctypes.POINTER(MlpParams), vp, vp]
+    L.n3dt_render_workspace_bytes.restype = sz
+    L.n3dt_render_workspace_bytes.argtypes = [ctypes.POINTER(Geom), ci]
+    L.n3dt_render_fwd.restype = ci
+    L.n3dt_render_fwd.argtypes = [ctypes.POINTER(Geom), ci, vp, ctypes.POINTER(MlpParams)] + [vp] * 14 + [vp, sz, vp]
+    L.n3dt_neural_render_workspace_bytes.restype = sz
+    L.n3dt_neural_render_workspace_bytes.argtypes = [ctypes.POINTER(Geom), ci]
+    L.n3dt_neural_render_fwd.restype = ci
+    L.n3dt_neural_render_fwd.argtypes = [ctypes.POINTER(Geom), ci, ctypes.POINTER(RenderParams), vp, vp, vp, sz, vp]
+    L.n3dt_chw_to_hwc.restype = ci
+    L.n3dt_chw_to_hwc.argtypes = [ci, ci, vp, vp, vp]
+    if L.n3dt_abi_version() != 1:
+        raise N3dtError("libn3dt.so ABI version mismatch")
+    _LIB = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise N3dtError("%s failed (%d): %s" % (what, rc, lib().n3dt_last_error().decode()))

@@ -1,0 +1,274 @@
+"""HeadNeRFNet: the host-side mirror of the reference module, running on libn3dt.so.
+
+Same constructor, same forward() signature / keyword names, same result dict and the same
+state-dict keys and shapes as the reference (NetWorks/HeadNeRFNet.py:10-207), so
+`talker_trainer.py` needs only its import line changed.  Everything between the
+inputs and the two images is computed by hand-written gfx950 kernels behind the C ABI of
+include/n3dt.h; there is no eager-PyTorch or CPU fallback -- a missing library or a CPU tensor
+raises.
+
+Sub-modules keep the reference's attribute names (sample_func, vp_encoder, fg_CD_predictor,
+calc_color_func, neural_render) so the inner seams stay addressable.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops, synthetic
+
+
+class _Conv1x1(nn.Module):
+    """Parameter holder with nn.Conv2d(k=1) state-dict keys/shapes ([out,in,1,1], [out])."""
+
+    def __init__(self, cin, cout, w_init, b_init="default_b"):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, 1, 1))
+        self.bias = nn.Parameter(torch.empty(cout))
+        self.reset(w_init, b_init)
+
+    def reset(self, w_init, b_init):
+        cout, cin = self.weight.shape[0], self.weight.shape[1]
+        with torch.no_grad():
+            if w_init == "xavier":  # reference: models.py:8-11 (_xavier_init)
+                a = math.sqrt(6.0 / (cin + cout))
+            else:  # nn.Conv2d default, kaiming_uniform(a=sqrt(5))
+                a = 1.0 / math.sqrt(cin)
+            self.weight.uniform_(-a, a)
+            if b_init == "zero":
+                self.bias.zero_()
+            else:
+                self.bias.uniform_(-1.0 / math.sqrt(cin), 1.0 / math.sqrt(cin))
+
+    def w2d(self):
+        return self.weight.view(self.weight.shape[0], self.weight.shape[1])
+
+
+class MLPforNeRF(nn.Module):
+    """Parameters of the latent-conditioned MLP (reference: NetWorks/models.py:13-59)."""
+
+    def __init__(self, vp_channels, vd_channels, n_layers=8, h_channel=256, res_nfeat=3, audio_dim=64):
+        super().__init__()
+        assert n_layers == 8, "the fused kernels are built for the 8-layer trunk"
+        self.vp_channels, self.vd_channels = vp_channels, vd_channels
+        self.h_channel, self.res_nfeat, self.audio_dim = h_channel, res_nfeat, audio_dim
+        self.n_layers = n_layers
+        self.skips = [n_layers // 2]
+        self.add_module("FeaExt_module_0", _Conv1x1(vp_channels + audio_dim, h_channel, "default_w"))
+        for i in range(n_layers - 1):
+            cin = h_channel + vp_channels if i in self.skips else h_channel
+            self.add_module("FeaExt_module_%d" % (i + 1), _Conv1x1(cin, h_channel, "xavier"))
+        self.add_module("density_module", _Conv1x1(h_channel, 1, "xavier", "zero"))
+        self.add_module("RGB_layer_0", _Conv1x1(h_channel, h_channel, "xavier"))
+        self.add_module("RGB_layer_1", _Conv1x1(h_channel + vd_channels, h_channel // 2, "default_w"))
+        self.add_module("RGB_layer_2", _Conv1x1(h_channel // 2, res_nfeat, "default_w"))
+
+    def layers(self):
+        return [self._modules[n] for n in _lib.MLP_ORDER]
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError(
+            "the per-sample [B,C,N_r,N_s] MLP output is never materialised by the fused kernel; "
+            "call HeadNeRFNet.render_features() for the composited result")
+
+
+class Blur(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("f", torch.tensor([1.0, 2.0, 1.0]))
+
+
+class PixelShuffleUpsample(nn.Module):
+    """Parameters of one upsample block (reference: NetWorks/PixelShuffleUpsample.py:21-33)."""
+
+    def __init__(self, in_feature):
+        super().__init__()
+        self.in_feature = in_feature
+        self.layer_1 = _Conv1x1(in_feature, in_feature * 2, "default_w")
+        self.layer_2 = _Conv1x1(in_feature * 2, in_feature * 4, "default_w")
+        self.blur_layer = Blur()
+
+
+class NeuralRenderer(nn.Module):
+    """2-D renderer, feature map -> RGB (reference: NetWorks/neural_renderer.py:11-91)."""
+
+    def __init__(self, bg_type="white", feat_nc=256, out_dim=3, final_actvn=True, min_feat=32, featmap_size=32,
+                 img_size=256, **kwargs):
+        super().__init__()
+        assert out_dim == 3 and final_actvn and min_feat == 32
+        self.bg_type = bg_type
+        self.featmap_size = featmap_size
+        self.n_feat = feat_nc
+        self.out_dim = out_dim
+        self.n_blocks = int(math.log2(img_size) - math.log2(featmap_size))
+        self.min_feat = min_feat
+        nf, nb = feat_nc, self.n_blocks
+        if bg_type == "white":
+            bg = torch.ones((1, nf, featmap_size, featmap_size), dtype=torch.float32)
+        elif bg_type == "black":
+            bg = torch.zeros((1, nf, featmap_size, featmap_size), dtype=torch.float32)
+        else:
+            raise ValueError("Error bg_type")  # the reference prints and exit(0)s here (neural_renderer.py:37-40)
+        self.register_parameter("bg_featmap", nn.Parameter(bg))
+        self.feat_upsample_list = nn.ModuleList([PixelShuffleUpsample(max(nf // (2 ** i), min_feat)) for i in range(nb)])
+        self.rgb_upsample = nn.ModuleList([nn.Identity(), Blur()])  # keys: rgb_upsample.1.f
+        self.feat_2_rgb_list = nn.ModuleList(
+            [_Conv1x1(nf, out_dim, "default_w")] +
+            [_Conv1x1(max(nf // (2 ** (i + 1)), min_feat), out_dim, "default_w") for i in range(nb)])
+        self.feat_layers = nn.ModuleList(
+            [_Conv1x1(max(nf // (2 ** i), min_feat), max(nf // (2 ** (i + 1)), min_feat), "default_w") for i in range(nb)])
+
+    def get_bg_featmap(self):
+        return self.bg_featmap
+
+    def _geom(self, nb):
+        return ops.make_geom(nb, self.featmap_size ** 2, 1, 384, self.n_feat, 1, 1, 0, self.featmap_size, self.n_blocks, 0, 0)
+
+    def _rparams(self):
+        def wb(m):
+            return (m.w2d().detach().contiguous(), m.bias.detach().contiguous())
+        return ops.render_params([wb(m) for m in self.feat_2_rgb_list], [wb(m.layer_1) for m in self.feat_upsample_list],
+                                 [wb(m.layer_2) for m in self.feat_upsample_list], [wb(m) for m in self.feat_layers])
+
+    def render_hwc(self, featmap_hwc):
+        """[nb, fs, fs, C] ray-major feature maps -> [nb, 3, P, P]"""
+        nb = featmap_hwc.shape[0]
+        return ops.neural_render_fwd(self._geom(nb), nb, self._rparams(), featmap_hwc.contiguous())
+
+    def forward(self, x):
+        """x: [nb, C, fs, fs] like the reference module."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("NeuralRenderer backward is not built yet; call under torch.no_grad()")
+        nb, C, fs, _ = x.shape
+        hwc = torch.stack([ops.chw_to_hwc(x[i].contiguous(), C, fs * fs) for i in range(nb)]).view(nb, fs, fs, C)
+        return self.render_hwc(hwc)
+
+
+class _Seam(nn.Module):
+    """Parameter-less seam kept for attribute compatibility (sample_func / vp_encoder / calc_color_func)."""
+
+    def __init__(self, what):
+        super().__init__()
+        self.what = what
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("%s is fused into n3dt_render_fwd; use HeadNeRFNet.render_features()" % self.what)
+
+
+class HeadNeRFNet(nn.Module):
+    def __init__(self, opt, include_vd, hier_sampling, include_gaze=False, eye_gaze_dim=2, audio_dim=64, precision="fp32"):
+        super().__init__()
+        if hier_sampling:
+            # the reference's fine branch raises TypeError at its call site (HeadNeRFNet.py:182-185)
+            raise NotImplementedError("hier_sampling=True is unreachable in the reference and not built here")
+        if include_vd:
+            raise NotImplementedError("include_vd=True is never used by the reference's callers and not built here")
+        self.hier_sampling = hier_sampling
+        self.include_vd = include_vd
+        self.include_gaze = include_gaze
+        self.eye_gaze_dim = eye_gaze_dim
+        self.audio_dim = audio_dim
+        self.precision = precision
+        self._build_info(opt)
+        self._build_tool_funcs()
+        self._pack_cache = {}
+
+    def _build_info(self, opt):
+        self.num_sample_coarse = opt.num_sample_coarse
+        self.num_sample_fine = opt.num_sample_fine
+        self.vp_n_freqs = 10
+        self.include_input_for_vp_embeder = True
+        self.mlp_h_channel = opt.mlp_hidden_nchannels
+        self.base_shape_code_dims = opt.iden_code_dims + opt.expr_code_dims
+        self.base_appea_code_dims = opt.text_code_dims + opt.illu_code_dims
+        self.featmap_size = opt.featmap_size
+        self.featmap_nc = opt.featmap_nc
+        self.pred_img_size = opt.pred_img_size
+        self.opt = opt
+
+    def _build_tool_funcs(self):
+        vp_channels = self.base_shape_code_dims + self.vp_n_freqs * 6 + 3
+        if self.include_gaze:
+            vp_channels += self.eye_gaze_dim
+        vd_channels = self.base_appea_code_dims
+        self.vp_encoder = _Seam("Embedder")
+        self.sample_func = _Seam("GenSamplePoints")
+        self.fg_CD_predictor = MLPforNeRF(vp_channels=vp_channels, vd_channels=vd_channels, h_channel=self.mlp_h_channel,
+                                          res_nfeat=self.featmap_nc, audio_dim=self.audio_dim)
+        self.calc_color_func = _Seam("CalcRayColor")
+        self.neural_render = NeuralRenderer(bg_type=self.opt.bg_type, feat_nc=self.featmap_nc, out_dim=3, final_actvn=True,
+                                            min_feat=32, featmap_size=self.featmap_size, img_size=self.pred_img_size)
+
+    # ------------------------------------------------------------------------------------------
+    def _shape_dim(self):
+        return self.base_shape_code_dims + (self.eye_gaze_dim if self.include_gaze else 0)
+
+    def _geom(self, batch, n_rays, xy):
+        return ops.make_geom(batch, n_rays, self.num_sample_coarse, self.mlp_h_channel, self.featmap_nc, self._shape_dim(),
+                             self.base_appea_code_dims, self.audio_dim, self.featmap_size, self.neural_render.n_blocks,
+                             self.opt.world_z1, self.opt.world_z2, xy.stride())
+
+    def _mlp_params(self):
+        layers = self.fg_CD_predictor.layers()
+        ws = [m.w2d().detach() for m in layers]
+        bs = [m.bias.detach() for m in layers]
+        return ops.mlp_params(ws, bs), ws, bs
+
+    def _packed(self, geom, precision, params, ws, bs):
+        """Packed weights, re-packed whenever the optimizer (or a load) touched a parameter."""
+        key = (precision, ws[0].device.index)
+        ver = tuple((t.data_ptr(), t._version) for t in ws + bs)
+        hit = self._pack_cache.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, ops.pack_mlp(geom, precision, params, ws[0].device))
+            self._pack_cache[key] = hit
+        return hit[1]
+
+    def render_features(self, batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
+                        t_rand=None, want_depth=False, want_weight=False, want_merge=True, precision=None):
+        """Rays -> composited feature map (seams a1..a7).  Outputs are ray-major [B, N_r, C]."""
+        prec = _lib.PRECISIONS[precision or self.precision]
+        B, tv, n_r = batch_xy.size()
+        assert tv == 2
+        xy = batch_xy if batch_xy.dtype == torch.float32 else batch_xy.float()
+        geom = self._geom(B, n_r, xy)
+        params, ws, bs = self._mlp_params()
+        packed = self._packed(geom, prec, params, ws, bs)
+        audio = ops._f32c(audiostyle) if self.audio_dim > 0 else None
+        out = ops.render_fwd(geom, prec, packed, params, xy, ops._f32c(batch_Rmats), ops._f32c(batch_Tvecs).view(B, 3),
+                             ops._f32c(batch_inv_inmats), ops._f32c(shape_code), ops._f32c(appea_code), audio,
+                             None if t_rand is None else ops._f32c(t_rand),
+                             self.neural_render.bg_featmap.detach().view(self.featmap_nc, -1) if want_merge else None,
+                             want_depth=want_depth, want_weight=want_weight, want_merge=want_merge)
+        return out
+
+    def _forward(self, for_train, batch_xy, batch_uv, audiostyle, bg_code, shape_code, appea_code, batch_Rmats,
+                 batch_Tvecs, batch_inv_inmats, dist_expr, t_rand=None):
+        batch_size, tv, n_r = batch_xy.size()
+        assert tv == 2
+        assert bg_code is None
+        if n_r != self.featmap_size ** 2:
+            raise ValueError("forward() renders an image, so N_r must equal featmap_size^2; "
+                             "use render_features() for free ray sets")
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
+                                        any(torch.is_tensor(t) and t.requires_grad for t in
+                                            (audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs))):
+            raise NotImplementedError("the backward kernels are not built yet; call under torch.no_grad()")
+        if for_train and t_rand is None:
+            # same generator consumption as the reference's torch.rand_like(zvals) (NetWorks/utils.py:77)
+            t_rand = torch.rand(batch_size, n_r, self.num_sample_coarse + 1, device=batch_xy.device, dtype=torch.float32)
+        out = self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
+                                   t_rand=t_rand, want_merge=True)
+        fs, C = self.featmap_size, self.featmap_nc
+        # the merged maps and the background map go through the 2-D renderer in one call (nb = B+1)
+        maps = torch.empty(batch_size + 1, fs, fs, C, dtype=torch.float32, device=batch_xy.device)
+        maps[:batch_size] = out["merge_feat"].view(batch_size, fs, fs, C)
+        ops.chw_to_hwc(self.neural_render.bg_featmap.detach().view(C, fs * fs), C, fs * fs, maps[batch_size].view(fs * fs, C))
+        imgs = self.neural_render.render_hwc(maps)
+        return {"coarse_dict": {"merge_img": imgs[:batch_size], "bg_img": imgs[batch_size:]}}
+
+    def forward(self, mode, batch_xy, batch_uv, audiostyle=None, bg_code=None, shape_code=None, appea_code=None,
+                batch_Rmats=None, batch_Tvecs=None, batch_inv_inmats=None, dist_expr=False, **kwargs):
+        assert mode in ["train", "test"]
+        return self._forward(mode == "train", batch_xy, batch_uv, audiostyle, bg_code, shape_code, appea_code,
+                             batch_Rmats, batch_Tvecs, batch_inv_inmats, dist_expr, t_rand=kwargs.get("t_rand"))

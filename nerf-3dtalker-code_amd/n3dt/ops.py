@@ -1,0 +1,139 @@
+"""Host-side launchers over the C ABI (include/n3dt.h).
+
+torch is used here for device memory, the current HIP stream and nothing else: every tensor is
+handed to libn3dt.so as a raw device pointer.  No CPU or eager-PyTorch fallback exists; calling
+these with CPU tensors raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import Geom, MlpParams, RenderParams, check, lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "libn3dt works on device memory only (no CPU fallback)"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32c(t):
+    """fp32, contiguous, detached view of a (small) tensor"""
+    return t.detach().to(dtype=torch.float32).contiguous()
+
+
+class _Workspace:
+    """Grow-only per-device scratch buffers, keyed by role (stream-ordered reuse)."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, key, nbytes, device):
+        k = (key, device.index)
+        b = self.buf.get(k)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            self.buf[k] = b
+        return b
+
+
+WORKSPACE = _Workspace()
+
+
+def make_geom(batch, n_rays, n_samples, hidden, feat_nc, shape_dim, appea_dim, audio_dim, featmap_size, n_blocks,
+              world_z1, world_z2, xy_strides=(0, 0, 0)):
+    g = Geom()
+    g.batch, g.n_rays, g.n_samples = int(batch), int(n_rays), int(n_samples)
+    g.hidden, g.feat_nc = int(hidden), int(feat_nc)
+    g.shape_dim, g.appea_dim, g.audio_dim = int(shape_dim), int(appea_dim), int(audio_dim)
+    g.featmap_size, g.n_blocks = int(featmap_size), int(n_blocks)
+    g.world_z1, g.world_z2 = float(world_z1), float(world_z2)
+    g.xy_stride_b, g.xy_stride_c, g.xy_stride_r = [int(s) for s in xy_strides]
+    return g
+
+
+def mlp_params(weights, biases):
+    """weights/biases: 12 fp32 contiguous device tensors in MLP_ORDER."""
+    p = MlpParams()
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+        assert b.is_cuda and b.dtype == torch.float32 and b.is_contiguous()
+        p.weight[i] = w.data_ptr()
+        p.bias[i] = b.data_ptr()
+    return p
+
+
+def render_params(to_rgb, psu1, psu2, feat):
+    """each argument: list of (weight, bias) fp32 contiguous device tensors"""
+    p = RenderParams()
+    for i, (w, b) in enumerate(to_rgb):
+        p.to_rgb_w[i], p.to_rgb_b[i] = w.data_ptr(), b.data_ptr()
+    for i, (w, b) in enumerate(psu1):
+        p.psu1_w[i], p.psu1_b[i] = w.data_ptr(), b.data_ptr()
+    for i, (w, b) in enumerate(psu2):
+        p.psu2_w[i], p.psu2_b[i] = w.data_ptr(), b.data_ptr()
+    for i, (w, b) in enumerate(feat):
+        p.feat_w[i], p.feat_b[i] = w.data_ptr(), b.data_ptr()
+    return p
+
+
+def pack_mlp(geom, precision, params, device):
+    nbytes = lib().n3dt_mlp_packed_bytes(ctypes.byref(geom), precision)
+    if nbytes == 0:
+        raise _lib.N3dtError("n3dt_mlp_packed_bytes: " + lib().n3dt_last_error().decode())
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    check(lib().n3dt_mlp_pack(ctypes.byref(geom), precision, ctypes.byref(params), _ptr(packed), _stream()), "n3dt_mlp_pack")
+    return packed
+
+
+def render_fwd(geom, precision, packed, params, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap,
+               want_depth=False, want_weight=False, want_merge=True):
+    """a1..a7 fused.  Returns dict(fg_feat [B,Nr,C], bg_alpha [B,Nr], depth?, weight?, merge_feat?)."""
+    dev = xy.device
+    B, Nr, Ns, C = geom.batch, geom.n_rays, geom.n_samples, geom.feat_nc
+    out = {
+        "fg_feat": torch.empty(B, Nr, C, dtype=torch.float32, device=dev),
+        "bg_alpha": torch.empty(B, Nr, dtype=torch.float32, device=dev),
+        "depth": torch.empty(B, Nr, dtype=torch.float32, device=dev) if want_depth else None,
+        "weight": torch.empty(B, Nr, Ns, dtype=torch.float32, device=dev) if want_weight else None,
+        "merge_feat": torch.empty(B, Nr, C, dtype=torch.float32, device=dev) if want_merge else None,
+    }
+    ws_bytes = lib().n3dt_render_workspace_bytes(ctypes.byref(geom), precision)
+    if ws_bytes == 0:
+        raise _lib.N3dtError("n3dt_render_workspace_bytes: " + lib().n3dt_last_error().decode())
+    ws = WORKSPACE.get("render", ws_bytes, dev)
+    rc = lib().n3dt_render_fwd(
+        ctypes.byref(geom), precision, _ptr(packed), ctypes.byref(params), _ptr(xy), _ptr(R), _ptr(T), _ptr(Kinv),
+        _ptr(shape), _ptr(appea), _ptr(audio), _ptr(t_rand), _ptr(bg_featmap) if want_merge else None,
+        _ptr(out["fg_feat"]), _ptr(out["bg_alpha"]), _ptr(out["depth"]), _ptr(out["weight"]), _ptr(out["merge_feat"]),
+        _ptr(ws), ws_bytes, _stream())
+    check(rc, "n3dt_render_fwd")
+    return out
+
+
+def neural_render_fwd(geom, nb, rparams, featmap):
+    """featmap [nb, fs, fs, C] (ray-major) -> img [nb, 3, P, P]"""
+    dev = featmap.device
+    P = geom.featmap_size << geom.n_blocks
+    img = torch.empty(nb, 3, P, P, dtype=torch.float32, device=dev)
+    ws_bytes = lib().n3dt_neural_render_workspace_bytes(ctypes.byref(geom), nb)
+    if ws_bytes == 0:
+        raise _lib.N3dtError("n3dt_neural_render_workspace_bytes: unsupported geometry")
+    ws = WORKSPACE.get("nr", ws_bytes, dev)
+    check(lib().n3dt_neural_render_fwd(ctypes.byref(geom), nb, ctypes.byref(rparams), _ptr(featmap), _ptr(img), _ptr(ws),
+                                       ws_bytes, _stream()), "n3dt_neural_render_fwd")
+    return img
+
+
+def chw_to_hwc(src, C, n, dst=None):
+    """[C, n] -> [n, C] on the device"""
+    if dst is None:
+        dst = torch.empty(n, C, dtype=torch.float32, device=src.device)
+    check(lib().n3dt_chw_to_hwc(C, n, _ptr(src), _ptr(dst), _stream()), "n3dt_chw_to_hwc")
+    return dst
