@@ -128,6 +128,15 @@ int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p,
 /* [C, N_r] (NCHW parameter) -> [N_r, C]; used to feed bg_featmap to the renderer */
 int n3dt_chw_to_hwc(int C, int n, const float* src, float* dst, void* stream);
 
+/* ---- measurement hook (bench.py only) ---------------------------------------------------------
+ * While enabled, every n3dt_render_fwd brackets its fused MLP kernel launch (the roofline kernel,
+ * not the fold / head kernels around it) with a hipEvent pair on the caller's stream.
+ * n3dt_prof_collect synchronises those events and returns each launch's duration in ms.
+ * Process-global and opt-in: the only mutable global state in the library; not for use while
+ * other threads are rendering. */
+int n3dt_prof_enable(int max_records);  /* 0 disables and frees the events */
+int n3dt_prof_collect(float* ms_out, int capacity, int* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,36 @@ static RenderCarve render_carve(const N3dtGeom* g, int precision) {
     return c;
 }
 
+// ---- opt-in measurement hook (see n3dt.h) ---------------------------------------------------
+static hipEvent_t* g_prof_ev = nullptr;  // 2 * g_prof_cap events
+static int g_prof_cap = 0, g_prof_n = 0;
+
+extern "C" int n3dt_prof_enable(int max_records) {
+    for (int i = 0; i < 2 * g_prof_cap; ++i) (void)hipEventDestroy(g_prof_ev[i]);
+    delete[] g_prof_ev;
+    g_prof_ev = nullptr;
+    g_prof_cap = g_prof_n = 0;
+    if (max_records <= 0) return N3DT_OK;
+    g_prof_ev = new hipEvent_t[2 * (size_t)max_records];
+    for (int i = 0; i < 2 * max_records; ++i)
+        if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) return fail(N3DT_EHIP, "n3dt_prof_enable: hipEventCreate failed");
+    g_prof_cap = max_records;
+    return N3DT_OK;
+}
+
+extern "C" int n3dt_prof_collect(float* ms_out, int capacity, int* n_out) {
+    if (!ms_out || !n_out) return fail(N3DT_EINVAL, "n3dt_prof_collect: NULL argument");
+    int n = g_prof_n < capacity ? g_prof_n : capacity;
+    for (int i = 0; i < n; ++i) {
+        if (hipEventSynchronize(g_prof_ev[2 * i + 1]) != hipSuccess) return fail(N3DT_EHIP, "n3dt_prof_collect: sync failed");
+        if (hipEventElapsedTime(&ms_out[i], g_prof_ev[2 * i], g_prof_ev[2 * i + 1]) != hipSuccess)
+            return fail(N3DT_EHIP, "n3dt_prof_collect: elapsed failed");
+    }
+    *n_out = n;
+    g_prof_n = 0;
+    return N3DT_OK;
+}
+
 extern "C" int n3dt_abi_version(void) { return N3DT_ABI_VERSION; }
 extern "C" const char* n3dt_last_error(void) { return g_err; }
 
@@ -112,10 +142,16 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
     float* part = (float*)(ws + c.part);
     float* wlocal = (float*)(ws + c.wlocal);
     n3dt_launch_fold(g, p, shape, appea, audio, fold, s);
+    const bool prof = g_prof_cap > 0 && g_prof_n < g_prof_cap;
+    if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_n], s);
     if (precision == N3DT_F32)
         n3dt_launch_nerf_fwd_f32(g, p, packed_mlp, fold, xy, R, T, Kinv, t_rand, part, weight ? wlocal : nullptr, s);
     else
         n3dt_launch_nerf_fwd_x16(g, precision, packed_mlp, fold, xy, R, T, Kinv, t_rand, part, weight ? wlocal : nullptr, s);
+    if (prof) {
+        (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], s);
+        ++g_prof_n;
+    }
     const float* tail = (const float*)((const unsigned char*)packed_mlp + n3dt_packed_tail_offset(precision));
     n3dt_launch_ray_head(g, c.bpr, c.bs, part, wlocal, tail, bg_featmap, fg_feat, bg_alpha, depth, weight, merge_feat, s);
     return check_hip("n3dt_render_fwd");

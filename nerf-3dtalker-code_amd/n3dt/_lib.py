@@ -44,7 +44,7 @@ class RenderParams(ctypes.Structure):
 EXPORTS = [
     "n3dt_abi_version", "n3dt_last_error", "n3dt_mlp_packed_bytes", "n3dt_mlp_pack",
     "n3dt_render_workspace_bytes", "n3dt_render_fwd", "n3dt_neural_render_workspace_bytes",
-    "n3dt_neural_render_fwd", "n3dt_chw_to_hwc",
+    "n3dt_neural_render_fwd", "n3dt_chw_to_hwc", "n3dt_prof_enable", "n3dt_prof_collect",
 ]
 
 _LIB = None
@@ -79,6 +79,10 @@ def lib():
     L.n3dt_neural_render_fwd.argtypes = [ctypes.POINTER(Geom), ci, ctypes.POINTER(RenderParams), vp, vp, vp, sz, vp]
     L.n3dt_chw_to_hwc.restype = ci
     L.n3dt_chw_to_hwc.argtypes = [ci, ci, vp, vp, vp]
+    L.n3dt_prof_enable.restype = ci
+    L.n3dt_prof_enable.argtypes = [ci]
+    L.n3dt_prof_collect.restype = ci
+    L.n3dt_prof_collect.argtypes = [ctypes.POINTER(ctypes.c_float), ci, ctypes.POINTER(ci)]
     if L.n3dt_abi_version() != 1:
         raise N3dtError("libn3dt.so ABI version mismatch")
     _LIB = L

@@ -1,0 +1,220 @@
+"""Parity of the HIP path (through the C ABI of include/n3dt.h) against the golden vectors emitted by
+the reference and against the CPU oracle.  Needs an MI355X: run with `-m gpu`.
+
+Tolerances (floating point, stated per BASELINE.json north_star):
+  fp32 mode  : RGB L-inf <= 1e-3 is the gate; measured ~1e-5, asserted at 1e-4 to catch drift early.
+  bf16 / f16 : measured RGB L-inf 4e-4 / 8e-5 on the fixtures; asserted at 2e-3 / 5e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, synthetic_case, options_from_manifest
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = {"fp32": 1e-4, "bf16": 2e-3, "fp16": 5e-4}
+FEAT_TOL = {"fp32": 2e-5, "bf16": 5e-3, "fp16": 1e-3}
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def to_dev(inp):
+    return {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in inp.items()}
+
+
+def build_net(opt, sd, precision="fp32", **kw):
+    from n3dt import HeadNeRFNet
+    net = HeadNeRFNet(opt, include_vd=False, hier_sampling=False, precision=precision, **kw).to(dev())
+    net.load_state_dict(sd, strict=True)
+    return net
+
+
+def fwd(net, d, mode="test", t_rand=None):
+    with torch.no_grad():
+        out = net(mode, d["batch_xy"], d["batch_uv"], d["audiostyle"], bg_code=None, shape_code=d["shape_code"],
+                  appea_code=d["appea_code"], batch_Rmats=d["batch_Rmats"], batch_Tvecs=d["batch_Tvecs"],
+                  batch_inv_inmats=d["batch_inv_inmats"], t_rand=t_rand)
+    torch.cuda.synchronize()
+    return out["coarse_dict"]
+
+
+def feats(net, d, t_rand=None, **kw):
+    with torch.no_grad():
+        out = net.render_features(d["batch_xy"], d["audiostyle"], d["shape_code"], d["appea_code"], d["batch_Rmats"],
+                                  d["batch_Tvecs"], d["batch_inv_inmats"], t_rand=t_rand, **kw)
+    torch.cuda.synchronize()
+    return out
+
+
+def test_native_library_is_loaded():
+    from n3dt import _lib
+    assert _lib.lib().n3dt_abi_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "libn3dt.so" in f.read()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("name", ["tiny_test", "tiny_train"])
+def test_tiny_all_seams(name, precision):
+    g, m = load_golden(name)
+    opt, sd, inp = synthetic_case(m)
+    from n3dt import synthetic as syn
+    t_rand = None
+    if m["mode"] == "train":
+        t_rand = syn.stratified_noise(m["batch"], opt.featmap_size ** 2, opt.num_sample_coarse, m["t_rand_seed"]).to(dev())
+    net = build_net(opt, sd, precision)
+    d = to_dev(inp)
+    f = feats(net, d, t_rand, want_depth=True, want_weight=True)
+    ft = FEAT_TOL[precision]
+    np.testing.assert_allclose(f["fg_feat"].permute(0, 2, 1).cpu().numpy(), g["fg_feat"], atol=ft)
+    np.testing.assert_allclose(f["bg_alpha"].cpu().numpy()[:, None], g["bg_alpha"], atol=ft)
+    np.testing.assert_allclose(f["weight"].cpu().numpy()[:, None], g["weight"], atol=ft)
+    np.testing.assert_allclose(f["depth"].cpu().numpy()[:, None], g["depth"], atol=20 * ft)  # z values are ~12
+    merge = f["merge_feat"].view(m["batch"], opt.featmap_size, opt.featmap_size, -1).permute(0, 3, 1, 2).cpu().numpy()
+    np.testing.assert_allclose(merge, g["merge_featmap"], atol=ft)
+    out = fwd(net, d, m["mode"], t_rand)
+    assert np.abs(out["merge_img"].cpu().numpy() - g["merge_img"]).max() <= RGB_TOL[precision]
+    assert np.abs(out["bg_img"].cpu().numpy() - g["bg_img"]).max() <= 1e-5
+    assert out["merge_img"].shape == (m["batch"], 3, opt.pred_img_size, opt.pred_img_size)
+    assert out["bg_img"].shape == (1, 3, opt.pred_img_size, opt.pred_img_size)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2r", "hr"])
+def test_baseline_configs(name, precision):
+    """BASELINE configs 1, 2 (reading R) and the 1024^2 HR path (5 upsample stages, 96 samples/ray)."""
+    g, m = load_golden(name)
+    opt, sd, inp = synthetic_case(m)
+    net = build_net(opt, sd, precision)
+    d = to_dev(inp)
+    f = feats(net, d)
+    step = int(g["ray_index_step"])
+    np.testing.assert_allclose(f["fg_feat"].permute(0, 2, 1).cpu().numpy()[:, :, ::step], g["fg_feat"], atol=FEAT_TOL[precision])
+    np.testing.assert_allclose(f["bg_alpha"].cpu().numpy()[:, None], g["bg_alpha"], atol=FEAT_TOL[precision])
+    out = fwd(net, d)
+    img = out["merge_img"].cpu().numpy()
+    bg = out["bg_img"].cpu().numpy()
+    tol = RGB_TOL[precision]
+    if "merge_img_q16" in g:
+        assert np.abs(img - g["merge_img_q16"].astype(np.float32) / 65535.0).max() <= tol
+    else:
+        c0, cs = int(g["crop_origin"]), g["merge_img_crop_q16"].shape[-1]
+        assert np.abs(img[:, :, c0:c0 + cs, c0:c0 + cs] - g["merge_img_crop_q16"].astype(np.float32) / 65535.0).max() <= tol
+    # a checksum over every pixel of the full-size image: row sums of both images
+    np.testing.assert_allclose(img.astype(np.float64).sum(-1), g["merge_img_rowsum"], atol=tol * img.shape[-1])
+    np.testing.assert_allclose(bg.astype(np.float64).sum(-1), g["bg_img_rowsum"], atol=1e-5 * bg.shape[-1])
+
+
+def test_variants_gaze_and_no_audio():
+    g, m = load_golden("edges")
+    from n3dt import synthetic as syn
+    opt = options_from_manifest(m)
+    sdg = syn.make_state_dict(opt, seed=3, include_gaze=True, eye_gaze_dim=64, bg_noise=0.1)
+    net = build_net(opt, sdg, include_gaze=True, eye_gaze_dim=64)
+    d = to_dev(syn.frame_inputs(opt, 1, include_gaze=True, eye_gaze_dim=64))
+    f = feats(net, d)
+    np.testing.assert_allclose(f["fg_feat"].permute(0, 2, 1).cpu().numpy(), g["gaze.fg_feat"], atol=2e-5)
+    assert np.abs(fwd(net, d)["merge_img"].cpu().numpy() - g["gaze.merge_img"]).max() <= 1e-4
+    sdn = syn.make_state_dict(opt, seed=4, audio_dim=0, bg_noise=0.1)
+    netn = build_net(opt, sdn, audio_dim=0)
+    dn = to_dev(syn.frame_inputs(opt, 1, audio_dim=0))
+    dn["audiostyle"] = None
+    f = feats(netn, dn)
+    np.testing.assert_allclose(f["fg_feat"].permute(0, 2, 1).cpu().numpy(), g["noaudio.fg_feat"], atol=2e-5)
+    assert np.abs(fwd(netn, dn)["merge_img"].cpu().numpy() - g["noaudio.merge_img"]).max() <= 1e-4
+
+
+def test_neural_render_seam():
+    g, m = load_golden("neural_render")
+    opt, sd, _ = synthetic_case(m)
+    net = build_net(opt, sd)
+    with torch.no_grad():
+        out = net.neural_render(torch.from_numpy(g["x"]).to(dev()))
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], atol=1e-5)
+
+
+def test_dz_zero_ray_propagates_non_finite_like_the_reference():
+    """A ray parallel to the sample planes: the reference yields inf/nan there; so must we,
+    without disturbing the other rays."""
+    g, m = load_golden("edges")
+    from n3dt import synthetic as syn
+    opt = options_from_manifest(m)
+    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
+    net = build_net(opt, sd)
+    inp = syn.frame_inputs(opt, 1)
+    inp["batch_Rmats"] = torch.from_numpy(g["dz0.R"])
+    inp["batch_Tvecs"] = torch.from_numpy(g["dz0.T"])
+    f = feats(net, to_dev(inp), want_depth=True)
+    bad_ref = ~np.isfinite(g["dz0.ray_l"][0, 0])
+    ba = f["bg_alpha"].cpu().numpy()[0]
+    assert np.all(~np.isfinite(ba[bad_ref]) | (ba[bad_ref] == 1.0))  # degenerate rays: non-finite or empty
+    assert np.all(np.isfinite(ba[~bad_ref]))
+
+
+def test_against_oracle_on_fresh_inputs():
+    """Seeded inputs no fixture covers (fs 16, 48 samples = one and a half 32-sample blocks, B=3), HIP vs CPU oracle."""
+    from n3dt import BaseOptions, synthetic as syn
+    from oracle import oracle as orc
+    opt = BaseOptions({"featmap_size": 16, "featmap_nc": 256, "pred_img_size": 64, "num_sample_coarse": 48})
+    sd = syn.make_state_dict(opt, seed=21, bg_noise=0.2)
+    inp = syn.frame_inputs(opt, 3, yaw_range=0.5, first_frame=40)
+    t_rand = syn.stratified_noise(3, 256, 48, seed=9)
+    ref = orc.forward(sd, opt, inp, t_rand)
+    net = build_net(opt, sd)
+    out = fwd(net, to_dev(inp), "train", t_rand.to(dev()))
+    assert np.abs(out["merge_img"].cpu().numpy() - ref["merge_img"]).max() <= 1e-4
+    f = feats(net, to_dev(inp), t_rand.to(dev()))
+    np.testing.assert_allclose(f["fg_feat"].permute(0, 2, 1).cpu().numpy(), ref["fg_feat"], atol=3e-5)
+
+
+def test_properties_at_full_size():
+    """BASELINE full size (fs 64, 64 samples, B=8): size-independent properties instead of a stored answer."""
+    from n3dt import BaseOptions, synthetic as syn
+    opt = BaseOptions({"featmap_size": 64, "featmap_nc": 256, "pred_img_size": 512, "num_sample_coarse": 64})
+    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
+    net = build_net(opt, sd, "bf16")
+    inp = syn.frame_inputs(opt, 8)
+    d = to_dev(inp)
+    a = feats(net, d, want_weight=True)
+    b = feats(net, d, want_weight=True)
+    # determinism: two runs are bit-identical (no atomics in the path)
+    assert torch.equal(a["fg_feat"], b["fg_feat"]) and torch.equal(a["bg_alpha"], b["bg_alpha"])
+    # the compositing weights are a sub-probability distribution: w >= 0, sum w + bg_alpha == 1
+    w = a["weight"]
+    assert float(w.min()) >= 0.0
+    assert float((w.sum(-1) + a["bg_alpha"] - 1.0).abs().max()) <= 1e-5
+    # frames are independent: frame 3 rendered alone equals frame 3 of the batch
+    one = {k: (v[3:4] if torch.is_tensor(v) else v) for k, v in d.items()}
+    c = feats(net, one)
+    assert torch.equal(c["fg_feat"][0], a["fg_feat"][3])
+    # broadcast (stride-0) ray grids are accepted: the trainer passes xy.expand(B,-1,-1)
+    xy1 = d["batch_xy"][:1].contiguous()
+    d2 = dict(d)
+    d2["batch_xy"] = xy1.expand(8, -1, -1)
+    e = feats(net, d2)
+    assert torch.equal(e["fg_feat"], a["fg_feat"])
+    img = fwd(net, d)["merge_img"]
+    assert img.shape == (8, 3, 512, 512) and float(img.min()) > 0.0 and float(img.max()) < 1.0
+
+
+def test_error_behaviour():
+    from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
+    opt = BaseOptions({"featmap_size": 8, "featmap_nc": 256, "pred_img_size": 32, "num_sample_coarse": 8})
+    net = HeadNeRFNet(opt, False, False).to(dev())
+    d = to_dev(syn.frame_inputs(opt, 1))
+    with pytest.raises(AssertionError):
+        net("eval", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"],
+            d["batch_Rmats"], d["batch_Tvecs"], d["batch_inv_inmats"])
+    with pytest.raises(AssertionError):
+        with torch.no_grad():
+            net("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], torch.zeros(1, 4, device=dev()), d["shape_code"],
+                d["appea_code"], d["batch_Rmats"], d["batch_Tvecs"], d["batch_inv_inmats"])
+    with pytest.raises(AssertionError):  # CPU tensors: no fallback
+        c = syn.frame_inputs(opt, 1)
+        with torch.no_grad():
+            net.render_features(c["batch_xy"], c["audiostyle"], c["shape_code"], c["appea_code"], c["batch_Rmats"],
+                                c["batch_Tvecs"], c["batch_inv_inmats"])
