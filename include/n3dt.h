@@ -119,11 +119,13 @@ int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, co
  * Replaces NeuralRenderer.forward (NetWorks/neural_renderer.py:72-91) including
  * PixelShuffleUpsample.forward (PixelShuffleUpsample.py:36-45) and Blur (…:15-18, kornia filter2d).
  *   featmap [nb, fs, fs, C] ray-major   ->   img [nb, 3, P, P], P = fs << n_blocks
+ * `precision` selects the arithmetic of the 1x1-conv GEMMs (N3DT_F32 exact; BF16/F16 inputs with
+ * fp32 accumulate); blur, bilinear and the RGB pyramid are always fp32.
  * `nb` is the number of feature maps in this call (the binding renders the B merged maps and the
  * background map together, nb = B+1; reference calls the module twice, HeadNeRFNet.py:109,113). */
 size_t n3dt_neural_render_workspace_bytes(const N3dtGeom* g, int nb);
-int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap, float* img,
-                           void* workspace, size_t workspace_bytes, void* stream);
+int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const float* featmap,
+                           float* img, void* workspace, size_t workspace_bytes, void* stream);
 
 /* [C, N_r] (NCHW parameter) -> [N_r, C]; used to feed bg_featmap to the renderer */
 int n3dt_chw_to_hwc(int C, int n, const float* src, float* dst, void* stream);

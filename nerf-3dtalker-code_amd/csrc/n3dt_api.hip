@@ -19,7 +19,7 @@ void n3dt_launch_nerf_fwd_f32(const N3dtGeom*, const N3dtMlpParams*, const void*
 void n3dt_launch_nerf_fwd_x16(const N3dtGeom*, int, const void*, const float*, const float*, const float*, const float*,
                               const float*, const float*, float*, float*, hipStream_t);
 size_t n3dt_nr_workspace_floats(const N3dtGeom*, int);
-void n3dt_launch_neural_render(const N3dtGeom*, int, const N3dtRenderParams*, const float*, float*, float*, hipStream_t);
+void n3dt_launch_neural_render(const N3dtGeom*, int, int, const N3dtRenderParams*, const float*, float*, float*, hipStream_t);
 }
 
 static thread_local char g_err[256] = "";
@@ -162,9 +162,10 @@ extern "C" size_t n3dt_neural_render_workspace_bytes(const N3dtGeom* g, int nb) 
     return n3dt_nr_workspace_floats(g, nb) * sizeof(float);
 }
 
-extern "C" int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap, float* img,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const float* featmap,
+                                      float* img, void* workspace, size_t workspace_bytes, void* stream) {
     if (!g || !p || !featmap || !img || !workspace) return fail(N3DT_EINVAL, "n3dt_neural_render_fwd: NULL argument");
+    if (precision != N3DT_F32 && precision != N3DT_BF16 && precision != N3DT_F16) return fail(N3DT_EINVAL, "unknown precision");
     if (nb < 1) return fail(N3DT_EINVAL, "n3dt_neural_render_fwd: nb < 1");
     if (g->n_blocks < 1 || g->n_blocks > N3DT_MAX_BLOCKS) return fail(N3DT_EINVAL, "n_blocks must be in 1..8");
     if (g->feat_nc != 256) return fail(N3DT_EINVAL, "only featmap_nc == 256 is built");
@@ -175,7 +176,7 @@ extern "C" int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, const N3dtRende
     for (int i = 0; i < g->n_blocks; ++i)
         if (!p->psu1_w[i] || !p->psu1_b[i] || !p->psu2_w[i] || !p->psu2_b[i] || !p->feat_w[i] || !p->feat_b[i])
             return fail(N3DT_EINVAL, "NULL neural-render block parameter");
-    n3dt_launch_neural_render(g, nb, p, featmap, img, (float*)workspace, (hipStream_t)stream);
+    n3dt_launch_neural_render(g, nb, precision, p, featmap, img, (float*)workspace, (hipStream_t)stream);
     return check_hip("n3dt_neural_render_fwd");
 }
 

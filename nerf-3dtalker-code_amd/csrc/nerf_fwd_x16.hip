@@ -22,6 +22,9 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef X16_PREFETCH
+#define X16_PREFETCH 1
+#endif
 #define X16_BS 32
 #define X16_CH 24                      // pieces per chunk (24 KiB)
 #define X16_PIECE 1024                 // bytes
@@ -141,6 +144,7 @@ __device__ __forceinline__ void x16_stage(WeightStream<WAVES>& ws, const float* 
     typedef typename X16<PREC>::frag frag;
     const int h = lane >> 5, c = lane & 31;
     float red[NB][32];
+    frag a_cur;
 #pragma unroll
     for (int ot = 0; ot < NT; ++ot) {
         f32x16 acc[NB];
@@ -159,8 +163,16 @@ __device__ __forceinline__ void x16_stage(WeightStream<WAVES>& ws, const float* 
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int p = ot * KS + ks;  // compile-time after unrolling
-            if (p % X16_CH == 0) ws.advance();
-            const frag a = *reinterpret_cast<const frag*>(ws.cur + (p % X16_CH) * X16_PIECE);
+            if (p % X16_CH == 0) {
+                ws.advance();
+                a_cur = *reinterpret_cast<const frag*>(ws.cur + (p % X16_CH) * X16_PIECE);
+            }
+#if X16_PREFETCH
+            // fetch the next piece of this chunk (it may belong to the next out tile) before issuing
+            // this piece's MFMA, so one fragment read is always in flight behind the matrix pipe
+            frag a_nxt = a_cur;
+            if ((p + 1) % X16_CH != 0) a_nxt = *reinterpret_cast<const frag*>(ws.cur + ((p + 1) % X16_CH) * X16_PIECE);
+#endif
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 frag b;
@@ -170,8 +182,17 @@ __device__ __forceinline__ void x16_stage(WeightStream<WAVES>& ws, const float* 
                 } else {
                     b = hin[nb][ks >= KPE ? ks - KPE : 0];
                 }
-                acc[nb] = X16<PREC>::mfma(a, b, acc[nb]);
+                acc[nb] = X16<PREC>::mfma(a_cur, b, acc[nb]);
             }
+#if X16_PREFETCH
+            a_cur = a_nxt;
+#if X16_PREFETCH > 1
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NB, 0);
+#endif
+#else
+            if ((p + 1) % X16_CH != 0) a_cur = *reinterpret_cast<const frag*>(ws.cur + ((p + 1) % X16_CH) * X16_PIECE);
+#endif
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libn3dt.so")
+LIB_PATH = os.environ.get("N3DT_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libn3dt.so")
 
 F32, BF16, F16 = 0, 1, 2
 PRECISIONS = {"fp32": F32, "f32": F32, "bf16": BF16, "fp16": F16, "f16": F16}
@@ -76,7 +76,7 @@ def lib():
     L.n3dt_neural_render_workspace_bytes.restype = sz
     L.n3dt_neural_render_workspace_bytes.argtypes = [ctypes.POINTER(Geom), ci]
     L.n3dt_neural_render_fwd.restype = ci
-    L.n3dt_neural_render_fwd.argtypes = [ctypes.POINTER(Geom), ci, ctypes.POINTER(RenderParams), vp, vp, vp, sz, vp]
+    L.n3dt_neural_render_fwd.argtypes = [ctypes.POINTER(Geom), ci, ci, ctypes.POINTER(RenderParams), vp, vp, vp, sz, vp]
     L.n3dt_chw_to_hwc.restype = ci
     L.n3dt_chw_to_hwc.argtypes = [ci, ci, vp, vp, vp]
     L.n3dt_prof_enable.restype = ci

@@ -130,10 +130,10 @@ class NeuralRenderer(nn.Module):
         return ops.render_params([wb(m) for m in self.feat_2_rgb_list], [wb(m.layer_1) for m in self.feat_upsample_list],
                                  [wb(m.layer_2) for m in self.feat_upsample_list], [wb(m) for m in self.feat_layers])
 
-    def render_hwc(self, featmap_hwc):
+    def render_hwc(self, featmap_hwc, precision="fp32"):
         """[nb, fs, fs, C] ray-major feature maps -> [nb, 3, P, P]"""
         nb = featmap_hwc.shape[0]
-        return ops.neural_render_fwd(self._geom(nb), nb, self._rparams(), featmap_hwc.contiguous())
+        return ops.neural_render_fwd(self._geom(nb), nb, self._rparams(), featmap_hwc.contiguous(), _lib.PRECISIONS[precision])
 
     def forward(self, x):
         """x: [nb, C, fs, fs] like the reference module."""
@@ -264,7 +264,7 @@ class HeadNeRFNet(nn.Module):
         maps = torch.empty(batch_size + 1, fs, fs, C, dtype=torch.float32, device=batch_xy.device)
         maps[:batch_size] = out["merge_feat"].view(batch_size, fs, fs, C)
         ops.chw_to_hwc(self.neural_render.bg_featmap.detach().view(C, fs * fs), C, fs * fs, maps[batch_size].view(fs * fs, C))
-        imgs = self.neural_render.render_hwc(maps)
+        imgs = self.neural_render.render_hwc(maps, self.precision)
         return {"coarse_dict": {"merge_img": imgs[:batch_size], "bg_img": imgs[batch_size:]}}
 
     def forward(self, mode, batch_xy, batch_uv, audiostyle=None, bg_code=None, shape_code=None, appea_code=None,

@@ -117,7 +117,7 @@ def render_fwd(geom, precision, packed, params, xy, R, T, Kinv, shape, appea, au
     return out
 
 
-def neural_render_fwd(geom, nb, rparams, featmap):
+def neural_render_fwd(geom, nb, rparams, featmap, precision=0):
     """featmap [nb, fs, fs, C] (ray-major) -> img [nb, 3, P, P]"""
     dev = featmap.device
     P = geom.featmap_size << geom.n_blocks
@@ -126,7 +126,7 @@ def neural_render_fwd(geom, nb, rparams, featmap):
     if ws_bytes == 0:
         raise _lib.N3dtError("n3dt_neural_render_workspace_bytes: unsupported geometry")
     ws = WORKSPACE.get("nr", ws_bytes, dev)
-    check(lib().n3dt_neural_render_fwd(ctypes.byref(geom), nb, ctypes.byref(rparams), _ptr(featmap), _ptr(img), _ptr(ws),
+    check(lib().n3dt_neural_render_fwd(ctypes.byref(geom), nb, precision, ctypes.byref(rparams), _ptr(featmap), _ptr(img), _ptr(ws),
                                        ws_bytes, _stream()), "n3dt_neural_render_fwd")
     return img
 

@@ -78,7 +78,7 @@ def test_tiny_all_seams(name, precision):
     np.testing.assert_allclose(merge, g["merge_featmap"], atol=ft)
     out = fwd(net, d, m["mode"], t_rand)
     assert np.abs(out["merge_img"].cpu().numpy() - g["merge_img"]).max() <= RGB_TOL[precision]
-    assert np.abs(out["bg_img"].cpu().numpy() - g["bg_img"]).max() <= 1e-5
+    assert np.abs(out["bg_img"].cpu().numpy() - g["bg_img"]).max() <= (1e-5 if precision == "fp32" else RGB_TOL[precision])
     assert out["merge_img"].shape == (m["batch"], 3, opt.pred_img_size, opt.pred_img_size)
     assert out["bg_img"].shape == (1, 3, opt.pred_img_size, opt.pred_img_size)
 
@@ -106,7 +106,7 @@ def test_baseline_configs(name, precision):
         assert np.abs(img[:, :, c0:c0 + cs, c0:c0 + cs] - g["merge_img_crop_q16"].astype(np.float32) / 65535.0).max() <= tol
     # a checksum over every pixel of the full-size image: row sums of both images
     np.testing.assert_allclose(img.astype(np.float64).sum(-1), g["merge_img_rowsum"], atol=tol * img.shape[-1])
-    np.testing.assert_allclose(bg.astype(np.float64).sum(-1), g["bg_img_rowsum"], atol=1e-5 * bg.shape[-1])
+    np.testing.assert_allclose(bg.astype(np.float64).sum(-1), g["bg_img_rowsum"], atol=(1e-5 if precision == "fp32" else tol) * bg.shape[-1])
 
 
 def test_variants_gaze_and_no_audio():
