@@ -32,6 +32,59 @@ FLOP_PER_POINT_EXECUTED = 2 * 1314816  # MFMA work actually issued per point (pa
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
 
 
+def bench_train(args, net, opt, d, dev, world, rank):
+    """BASELINE config 3: one reference-shaped train step = forward("train") -> 3 MSE terms -> backward -> Adam
+    (+ one flat-buffer RCCL all-reduce of the gradients when world > 1).  Exact-fp32 kernels."""
+    import torch
+    import torch.distributed as dist
+    from n3dt import parallel
+    from n3dt.train import data_losses, disk_mask
+    B = d["batch_xy"].shape[0]
+    net.precision = "fp32"
+    optim = torch.optim.Adam(net.parameters(), lr=1e-4)
+    gt = torch.full((B, 3, opt.pred_img_size, opt.pred_img_size), 0.5, device=dev)
+    mask = disk_mask(B, opt.pred_img_size).to(dev)
+    if world > 1:
+        parallel.broadcast_parameters(net)
+
+    def step():
+        pred = net("train", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"],
+                   d["batch_Rmats"], d["batch_Tvecs"], d["batch_inv_inmats"])
+        t = data_losses(pred["coarse_dict"], gt, mask)
+        loss = t["bg_loss"] + t["head_loss"] + t["nonhead_loss"]
+        optim.zero_grad()
+        loss.backward()
+        parallel.allreduce_gradients(net.parameters(), world)
+        optim.step()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.destroy_process_group()
+    elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "trained frames/sec @512^2 x 64 samples/ray (fwd+bwd+Adam)", "value": world * B * args.steps / elapsed,
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": "cfg3: %d heads/GPU/step, 64x64 rays x 64 samples -> 512x512, 3 MSE terms, Adam" % B,
+                       "parallelism": "frames sharded over %d rank(s), one flat gradient all-reduce per step" % world},
+        }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,6 +94,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--rays", default="R", choices=["R", "N"],
                     help="R: rays = featmap_size^2 (reference-faithful); N: 512^2 rays, feature stage only")
+    ap.add_argument("--mode", default="render", choices=["render", "train"],
+                    help="render: forward-only (BASELINE config 2, the headline); train: fwd+loss+bwd+Adam (config 3, fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -66,13 +121,16 @@ def main():
     sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
     net = HeadNeRFNet(opt, include_vd=False, hier_sampling=False, precision=args.precision).to(dev)
     net.load_state_dict(sd, strict=True)
-    B = args.batch
+    B = args.batch if args.mode == "render" else min(args.batch, 2)
     n_side = 512 if args.rays == "N" else None
     # every rank renders its own frames: frame indices rank*B .. rank*B+B-1
     inp = syn.frame_inputs(opt, B, n_side=n_side, first_frame=rank * B)
     d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
     n_rays = d["batch_xy"].shape[-1]
     points_per_step = B * n_rays * ns
+
+    if args.mode == "train":
+        return bench_train(args, net, opt, d, dev, world, rank)
 
     def step():
         if args.rays == "R":

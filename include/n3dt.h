@@ -83,6 +83,24 @@ typedef struct N3dtRenderParams {
     const float* feat_b[N3DT_MAX_BLOCKS];
 } N3dtRenderParams;
 
+/* Gradient buffers, same shapes and order as the parameters; every training entry point ACCUMULATES (+=)
+ * into them, so the caller zeroes them (or passes PyTorch's .grad tensors to accumulate across calls). */
+typedef struct N3dtMlpGrads {
+    float* weight[N3DT_MLP_LAYERS];
+    float* bias[N3DT_MLP_LAYERS];
+} N3dtMlpGrads;
+
+typedef struct N3dtRenderGrads {
+    float* to_rgb_w[N3DT_MAX_BLOCKS + 1];
+    float* to_rgb_b[N3DT_MAX_BLOCKS + 1];
+    float* psu1_w[N3DT_MAX_BLOCKS];
+    float* psu1_b[N3DT_MAX_BLOCKS];
+    float* psu2_w[N3DT_MAX_BLOCKS];
+    float* psu2_b[N3DT_MAX_BLOCKS];
+    float* feat_w[N3DT_MAX_BLOCKS];
+    float* feat_b[N3DT_MAX_BLOCKS];
+} N3dtRenderGrads;
+
 int n3dt_abi_version(void);
 const char* n3dt_last_error(void);
 
@@ -126,6 +144,40 @@ int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, co
 size_t n3dt_neural_render_workspace_bytes(const N3dtGeom* g, int nb);
 int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const float* featmap,
                            float* img, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- training path (fwd -> loss -> backward) -----------------------------------
+ * Exact fp32.  The forward keeps the per-layer activations in `saved` (caller-owned, sized by the
+ * *_saved_bytes query) for the matching backward call; `workspace` is scratch.
+ *
+ * n3dt_render_train_fwd: same mathematics and outputs as n3dt_render_fwd (fg_feat, bg_alpha, depth?, merge_feat?).
+ * n3dt_render_bwd: given dL/d(merge_feat) (and optionally dL/d(fg_feat), dL/d(bg_alpha), both nullable),
+ *   accumulates parameter gradients into `grads`, adds dL/d(bg_featmap) [C,N_r] into d_bg_featmap (nullable)
+ *   and writes dL/d(shape) [B,shape_dim], dL/d(appea) [B,appea_dim], dL/d(audio) [B,audio_dim] (each nullable).
+ *   Differentiates NetWorks/models.py:62-87, NetWorks/utils.py:268-309, NetWorks/HeadNeRFNet.py:84-112,149-152.
+ *   (Gradients to the cameras, SURVEY 8f-1, are not built yet.) */
+size_t n3dt_render_train_saved_bytes(const N3dtGeom* g);
+size_t n3dt_render_train_workspace_bytes(const N3dtGeom* g);
+int n3dt_render_train_fwd(const N3dtGeom* g, const void* packed_mlp, const N3dtMlpParams* p,
+                          const float* xy, const float* R, const float* T, const float* Kinv,
+                          const float* shape, const float* appea, const float* audio, const float* t_rand,
+                          const float* bg_featmap, float* fg_feat, float* bg_alpha, float* depth, float* merge_feat,
+                          void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream);
+int n3dt_render_bwd(const N3dtGeom* g, const N3dtMlpParams* p, const N3dtMlpGrads* grads,
+                    const float* shape, const float* appea, const float* audio, const float* bg_featmap,
+                    const float* d_merge_feat, const float* d_fg_feat, const float* d_bg_alpha,
+                    const void* saved, size_t saved_bytes,
+                    float* d_bg_featmap, float* d_shape, float* d_appea, float* d_audio,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Neural renderer with saved activations, and its backward (differentiates NetWorks/neural_renderer.py:72-91,
+ * NetWorks/PixelShuffleUpsample.py:36-45).  d_featmap [nb,fs,fs,C] is overwritten; parameter gradients accumulate. */
+size_t n3dt_neural_render_train_saved_bytes(const N3dtGeom* g, int nb);
+size_t n3dt_neural_render_train_workspace_bytes(const N3dtGeom* g, int nb);
+int n3dt_neural_render_train_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap, float* img,
+                                 void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream);
+int n3dt_neural_render_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N3dtRenderGrads* grads,
+                           const float* featmap, const float* d_img, const void* saved, size_t saved_bytes,
+                           float* d_featmap, void* workspace, size_t workspace_bytes, void* stream);
 
 /* [C, N_r] (NCHW parameter) -> [N_r, C]; used to feed bg_featmap to the renderer */
 int n3dt_chw_to_hwc(int C, int n, const float* src, float* dst, void* stream);

@@ -1,0 +1,131 @@
+// fp32 MFMA GEMM (see gemm32.h): 128x128x16 tile, 4 waves x (2x2) 32x32 accumulators,
+// operands staged k-major in LDS so that the A/B fragment reads are conflict-free ds_read_b32.
+#include "gemm32.h"
+
+#include "n3dt_device.h"
+
+#define G_BM 128
+#define G_BN 128
+#define G_BK 16
+#define G_LD (G_BM + 4)
+
+// stage a [128 rows x 16 k] operand tile into LDS as T[k][row]
+__device__ __forceinline__ void g32_stage(float (*T)[G_LD], const float* __restrict__ P, long ld, int kmajor, int row0, int nrows,
+                                          int k0, int kend, int tid) {
+    if (!kmajor) {
+        // rows are K-contiguous: thread -> (row, 8 consecutive k)
+        const int row = tid >> 1, kq = (tid & 1) * 8;
+        const int r = row0 + row;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+        if (r < nrows) {
+            const float* src = P + (long)r * ld + k0 + kq;
+            if (k0 + kq + 8 <= kend && ((((size_t)src) & 15) == 0)) {
+                f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+                v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (k0 + kq + j < kend) v[j] = src[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) T[kq + j][row] = v[j];
+    } else {
+        // k-major: thread -> (k row, 8 consecutive operand rows)
+        const int kr = tid >> 4, c8 = (tid & 15) * 8;
+        const int k = k0 + kr;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+        if (k < kend) {
+            const float* src = P + (long)k * ld + row0 + c8;
+            if (row0 + c8 + 8 <= nrows && ((((size_t)src) & 15) == 0)) {
+                f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+                v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (row0 + c8 + j < nrows) v[j] = src[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) T[kr][c8 + j] = v[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm32_kernel(Gemm32 g) {
+    __shared__ float As[G_BK][G_LD];
+    __shared__ float Bs[G_BK][G_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.x * G_BM, n0 = blockIdx.y * G_BN;
+    int kbeg = 0, kend = g.K;
+    if (g.split_k > 1) {
+        const int per = ((g.K + g.split_k - 1) / g.split_k + G_BK - 1) / G_BK * G_BK;
+        kbeg = blockIdx.z * per;
+        kend = min(g.K, kbeg + per);
+        if (kbeg >= kend) return;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int k0 = kbeg; k0 < kend; k0 += G_BK) {
+        __syncthreads();
+        g32_stage(As, g.A, g.lda, g.a_kmajor, m0, g.M, k0, kend, tid);
+        g32_stage(Bs, g.B, g.ldb, g.b_kmajor, n0, g.N, k0, kend, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < G_BK; kk += 2) {
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = As[kk + (lane >> 5)][wr * 64 + t * 32 + (lane & 31)];
+                b[t] = Bs[kk + (lane >> 5)][wc * 64 + t * 32 + (lane & 31)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const bool first_slice = (g.split_k <= 1) || blockIdx.z == 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wc * 64 + j * 32 + (lane & 31);
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (m >= g.M) continue;
+                float v = acc[i][j][reg];
+                if (g.bias && first_slice) v += g.bias[(g.bias_group_rows ? (long)(m / g.bias_group_rows) * g.bias_ld : 0) + n];
+                if (g.act == G32_ACT_RELU) v = fmaxf(v, 0.0f);
+                else if (g.act == G32_ACT_LRELU) v = v > 0.0f ? v : 0.2f * v;
+                if (g.gate_act != G32_ACT_NONE) {
+                    const float y = g.gate[(long)m * g.ldgate + n];
+                    if (g.gate_act == G32_ACT_RELU) v = y > 0.0f ? v : 0.0f;
+                    else v = y > 0.0f ? v : 0.2f * v;
+                }
+                float* dst = g.C + (long)m * g.ldc + n;
+                if (g.split_k > 1) atomicAdd(dst, v);
+                else if (g.accumulate) *dst += v;
+                else *dst = v;
+            }
+    }
+}
+
+void n3dt_gemm32(const Gemm32& g, hipStream_t stream) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
+    dim3 grid((g.M + G_BM - 1) / G_BM, (g.N + G_BN - 1) / G_BN, g.split_k > 1 ? g.split_k : 1);
+    hipLaunchKernelGGL(gemm32_kernel, grid, dim3(256), 0, stream, g);
+}

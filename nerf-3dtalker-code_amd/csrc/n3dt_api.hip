@@ -19,6 +19,19 @@ void n3dt_launch_nerf_fwd_f32(const N3dtGeom*, const N3dtMlpParams*, const void*
 void n3dt_launch_nerf_fwd_x16(const N3dtGeom*, int, const void*, const float*, const float*, const float*, const float*,
                               const float*, const float*, float*, float*, hipStream_t);
 size_t n3dt_nr_workspace_floats(const N3dtGeom*, int);
+size_t n3dt_train_saved_floats(const N3dtGeom*);
+size_t n3dt_train_ws_floats(const N3dtGeom*);
+void n3dt_launch_train_fwd(const N3dtGeom*, const N3dtMlpParams*, const float*, const float*, const float*, const float*, const float*,
+                           const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, float*,
+                           float*, hipStream_t);
+void n3dt_launch_train_bwd(const N3dtGeom*, const N3dtMlpParams*, const N3dtMlpGrads*, const float*, const float*, const float*,
+                           const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, float*,
+                           hipStream_t);
+size_t n3dt_nr_train_saved_floats(const N3dtGeom*, int);
+size_t n3dt_nr_train_ws_floats(const N3dtGeom*, int);
+void n3dt_launch_nr_train_fwd(const N3dtGeom*, int, const N3dtRenderParams*, const float*, float*, float*, float*, hipStream_t);
+void n3dt_launch_nr_bwd(const N3dtGeom*, int, const N3dtRenderParams*, const N3dtRenderGrads*, const float*, const float*, const float*,
+                        float*, float*, hipStream_t);
 void n3dt_launch_neural_render(const N3dtGeom*, int, int, const N3dtRenderParams*, const float*, float*, float*, hipStream_t);
 }
 
@@ -184,4 +197,103 @@ extern "C" int n3dt_chw_to_hwc(int C, int n, const float* src, float* dst, void*
     if (C < 1 || n < 1 || !src || !dst) return fail(N3DT_EINVAL, "n3dt_chw_to_hwc: bad argument");
     n3dt_launch_chw_to_hwc(C, n, src, dst, (hipStream_t)stream);
     return check_hip("n3dt_chw_to_hwc");
+}
+
+// ---- training path -----------------------------------------------------------------------------
+static int check_train_geom(const N3dtGeom* g) {
+    int rc = check_geom(g, N3DT_F32);
+    if (rc) return rc;
+    if ((size_t)g->batch * g->n_rays * g->n_samples > (size_t)1 << 30) return fail(N3DT_EINVAL, "training path: more than 2^30 sample points");
+    return N3DT_OK;
+}
+
+extern "C" size_t n3dt_render_train_saved_bytes(const N3dtGeom* g) {
+    if (check_train_geom(g) != N3DT_OK) return 0;
+    return n3dt_train_saved_floats(g) * sizeof(float);
+}
+extern "C" size_t n3dt_render_train_workspace_bytes(const N3dtGeom* g) {
+    if (check_train_geom(g) != N3DT_OK) return 0;
+    return n3dt_train_ws_floats(g) * sizeof(float);
+}
+
+extern "C" int n3dt_render_train_fwd(const N3dtGeom* g, const void* packed_mlp, const N3dtMlpParams* p, const float* xy, const float* R,
+                                     const float* T, const float* Kinv, const float* shape, const float* appea, const float* audio,
+                                     const float* t_rand, const float* bg_featmap, float* fg_feat, float* bg_alpha, float* depth,
+                                     float* merge_feat, void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    int rc = check_train_geom(g);
+    if (rc) return rc;
+    if (!packed_mlp || !p || !xy || !R || !T || !Kinv || !shape || !appea || !fg_feat || !saved || !workspace)
+        return fail(N3DT_EINVAL, "n3dt_render_train_fwd: NULL argument");
+    if (g->audio_dim > 0 && !audio) return fail(N3DT_EINVAL, "n3dt_render_train_fwd: audio is NULL but audio_dim > 0");
+    if (merge_feat && !bg_featmap) return fail(N3DT_EINVAL, "n3dt_render_train_fwd: merge_feat needs bg_featmap");
+    if (saved_bytes < n3dt_render_train_saved_bytes(g)) return fail(N3DT_EWORKSPACE, "n3dt_render_train_fwd: saved buffer too small");
+    if (workspace_bytes < n3dt_render_train_workspace_bytes(g)) return fail(N3DT_EWORKSPACE, "n3dt_render_train_fwd: workspace too small");
+    // the fp32 tail (W2^T, b2) sits at the same place in a packed buffer of any precision given to us as F32-packed
+    const float* tail = (const float*)((const unsigned char*)packed_mlp + n3dt_packed_tail_offset(N3DT_F32));
+    n3dt_launch_train_fwd(g, p, tail, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap, fg_feat, bg_alpha, depth, merge_feat,
+                          (float*)saved, (float*)workspace, (hipStream_t)stream);
+    return check_hip("n3dt_render_train_fwd");
+}
+
+extern "C" int n3dt_render_bwd(const N3dtGeom* g, const N3dtMlpParams* p, const N3dtMlpGrads* grads, const float* shape,
+                               const float* appea, const float* audio, const float* bg_featmap, const float* d_merge_feat,
+                               const float* d_fg_feat, const float* d_bg_alpha, const void* saved, size_t saved_bytes,
+                               float* d_bg_featmap, float* d_shape, float* d_appea, float* d_audio, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    int rc = check_train_geom(g);
+    if (rc) return rc;
+    if (!p || !grads || !shape || !appea || !saved || !workspace) return fail(N3DT_EINVAL, "n3dt_render_bwd: NULL argument");
+    if (!d_merge_feat && !d_fg_feat && !d_bg_alpha) return fail(N3DT_EINVAL, "n3dt_render_bwd: no incoming gradient");
+    if (d_merge_feat && !bg_featmap) return fail(N3DT_EINVAL, "n3dt_render_bwd: d_merge_feat needs bg_featmap");
+    if (g->audio_dim > 0 && !audio) return fail(N3DT_EINVAL, "n3dt_render_bwd: audio is NULL but audio_dim > 0");
+    for (int l = 0; l < N3DT_MLP_LAYERS; ++l)
+        if (!grads->weight[l] || !grads->bias[l]) return fail(N3DT_EINVAL, "n3dt_render_bwd: NULL gradient pointer");
+    if (saved_bytes < n3dt_render_train_saved_bytes(g)) return fail(N3DT_EWORKSPACE, "n3dt_render_bwd: saved buffer too small");
+    if (workspace_bytes < n3dt_render_train_workspace_bytes(g)) return fail(N3DT_EWORKSPACE, "n3dt_render_bwd: workspace too small");
+    n3dt_launch_train_bwd(g, p, grads, shape, appea, audio, bg_featmap, d_merge_feat, d_fg_feat, d_bg_alpha, (const float*)saved,
+                          d_bg_featmap, d_shape, d_appea, d_audio, (float*)workspace, (hipStream_t)stream);
+    return check_hip("n3dt_render_bwd");
+}
+
+static int check_nr(const N3dtGeom* g, int nb) {
+    if (!g) return fail(N3DT_EINVAL, "geometry is NULL");
+    if (nb < 1) return fail(N3DT_EINVAL, "nb < 1");
+    if (g->n_blocks < 1 || g->n_blocks > N3DT_MAX_BLOCKS) return fail(N3DT_EINVAL, "n_blocks must be in 1..8");
+    if (g->feat_nc != 256) return fail(N3DT_EINVAL, "only featmap_nc == 256 is built");
+    if (g->featmap_size < 2) return fail(N3DT_EINVAL, "featmap_size < 2 (reflect border needs 2 pixels)");
+    return N3DT_OK;
+}
+
+extern "C" size_t n3dt_neural_render_train_saved_bytes(const N3dtGeom* g, int nb) {
+    if (check_nr(g, nb) != N3DT_OK) return 0;
+    return n3dt_nr_train_saved_floats(g, nb) * sizeof(float);
+}
+extern "C" size_t n3dt_neural_render_train_workspace_bytes(const N3dtGeom* g, int nb) {
+    if (check_nr(g, nb) != N3DT_OK) return 0;
+    return n3dt_nr_train_ws_floats(g, nb) * sizeof(float);
+}
+
+extern "C" int n3dt_neural_render_train_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap, float* img,
+                                            void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_nr(g, nb);
+    if (rc) return rc;
+    if (!p || !featmap || !img || !saved || !workspace) return fail(N3DT_EINVAL, "n3dt_neural_render_train_fwd: NULL argument");
+    if (saved_bytes < n3dt_neural_render_train_saved_bytes(g, nb)) return fail(N3DT_EWORKSPACE, "neural render saved buffer too small");
+    if (workspace_bytes < n3dt_neural_render_train_workspace_bytes(g, nb)) return fail(N3DT_EWORKSPACE, "neural render workspace too small");
+    n3dt_launch_nr_train_fwd(g, nb, p, featmap, img, (float*)saved, (float*)workspace, (hipStream_t)stream);
+    return check_hip("n3dt_neural_render_train_fwd");
+}
+
+extern "C" int n3dt_neural_render_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N3dtRenderGrads* grads,
+                                      const float* featmap, const float* d_img, const void* saved, size_t saved_bytes, float* d_featmap,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_nr(g, nb);
+    if (rc) return rc;
+    if (!p || !grads || !featmap || !d_img || !saved || !d_featmap || !workspace)
+        return fail(N3DT_EINVAL, "n3dt_neural_render_bwd: NULL argument");
+    if (saved_bytes < n3dt_neural_render_train_saved_bytes(g, nb)) return fail(N3DT_EWORKSPACE, "neural render saved buffer too small");
+    if (workspace_bytes < n3dt_neural_render_train_workspace_bytes(g, nb)) return fail(N3DT_EWORKSPACE, "neural render workspace too small");
+    n3dt_launch_nr_bwd(g, nb, p, grads, featmap, d_img, (const float*)saved, d_featmap, (float*)workspace, (hipStream_t)stream);
+    return check_hip("n3dt_neural_render_bwd");
 }

@@ -1,0 +1,485 @@
+// Training path of the 2-D neural renderer: forward that keeps every stage's activations, and the
+// backward (adjoints of the 1x1 convs, pixel-shuffle + residual, reflect-border blur, bilinear x2 and
+// the RGB skip pyramid).  Exact fp32; every conv product is a gemm32 launch.
+//
+// Differentiates (reference): NetWorks/neural_renderer.py:72-91, NetWorks/PixelShuffleUpsample.py:36-45,
+// Blur :15-18 (kornia filter2d semantics).
+#include "gemm32.h"
+#include "n3dt_device.h"
+
+static inline int nr_ch(int C, int i) {
+    int v = C >> i;
+    return v < 32 ? 32 : v;
+}
+static inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+struct NrSaved {
+    size_t t1[N3DT_MAX_BLOCKS], tv[N3DT_MAX_BLOCKS], bl[N3DT_MAX_BLOCKS], net[N3DT_MAX_BLOCKS], img, total;
+};
+// t1: lrelu(layer_1 x) [M][2C]; tv: lrelu(layer_2 t1) before the residual [M][4C]; bl: blurred shuffled map [4M][C];
+// net: lrelu(feat conv) [4M][C/2] (= next stage's input); img: the sigmoid output (for sigmoid')
+static NrSaved nr_saved_layout(const N3dtGeom* g, int nb) {
+    NrSaved s;
+    size_t o = 0;
+    for (int i = 0; i < g->n_blocks; ++i) {
+        const size_t h = (size_t)g->featmap_size << i, M = (size_t)nb * h * h;
+        const size_t ci = nr_ch(g->feat_nc, i), co = nr_ch(g->feat_nc, i + 1);
+        s.t1[i] = o; o += al64(M * 2 * ci);
+        s.tv[i] = o; o += al64(M * 4 * ci);
+        s.bl[i] = o; o += al64(4 * M * ci);
+        s.net[i] = o; o += al64(4 * M * co);
+    }
+    const size_t P = (size_t)g->featmap_size << g->n_blocks;
+    s.img = o; o += al64((size_t)nb * 3 * P * P);
+    s.total = o;
+    return s;
+}
+
+struct NrWs {
+    size_t a, b, c, rgb0, rgb1, total;  // three big ping-pong buffers + two planar rgb gradient buffers
+};
+static NrWs nr_ws_layout(const N3dtGeom* g, int nb) {
+    NrWs w;
+    size_t big = 0;
+    for (int i = 0; i < g->n_blocks; ++i) {
+        const size_t h = (size_t)g->featmap_size << i, M = (size_t)nb * h * h;
+        const size_t ci = nr_ch(g->feat_nc, i);
+        if (4 * M * ci > big) big = 4 * M * ci;
+    }
+    const size_t P = (size_t)g->featmap_size << g->n_blocks;
+    size_t o = 0;
+    w.a = o; o += al64(big);
+    w.b = o; o += al64(big);
+    w.c = o; o += al64(big);
+    w.rgb0 = o; o += al64((size_t)nb * 3 * P * P);
+    w.rgb1 = o; o += al64((size_t)nb * 3 * P * P);
+    w.total = o;
+    return w;
+}
+
+extern "C" size_t n3dt_nr_train_saved_floats(const N3dtGeom* g, int nb) { return nr_saved_layout(g, nb).total; }
+extern "C" size_t n3dt_nr_train_ws_floats(const N3dtGeom* g, int nb) { return nr_ws_layout(g, nb).total; }
+
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// ---- forward pieces ---------------------------------------------------------------------------
+// tv [M][4C] (+ residual x.repeat) -> pixel-shuffled ps [4M][C]   (PixelShuffleUpsample.py:36,41-42)
+__global__ void nrt_shuffle_kernel(int nb, int H, int W, int C, const float* __restrict__ tv, const float* __restrict__ x,
+                                   float* __restrict__ ps) {
+    const size_t total = (size_t)nb * H * W * 4 * C;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    size_t opix = i / C;  // output pixel
+    const int ow = (int)(opix % (2 * W)), oh = (int)((opix / (2 * W)) % (2 * H)), img = (int)(opix / ((size_t)4 * W * H));
+    const int h = oh >> 1, di = oh & 1, w = ow >> 1, dj = ow & 1;
+    const size_t m = ((size_t)img * H + h) * W + w;
+    const int o = 4 * c + 2 * di + dj;
+    ps[i] = tv[m * 4 * C + o] + x[m * C + (o % C)];
+}
+
+__global__ void nrt_blur_kernel(int nb, int H, int W, int C, const float* __restrict__ x, float* __restrict__ y) {
+    const int c4 = C / 4;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nb * H * W * c4) return;
+    int cq = (int)(i % c4);
+    size_t pix = i / c4;
+    int w = (int)(pix % W), h = (int)((pix / W) % H), img = (int)(pix / ((size_t)W * H));
+    const float k[3] = {0.25f, 0.5f, 0.25f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int di = -1; di <= 1; ++di)
+#pragma unroll
+        for (int dj = -1; dj <= 1; ++dj) {
+            int hh = reflect1(h + di, H), ww = reflect1(w + dj, W);
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)img * H + hh) * W + ww) * C + 4 * cq);
+            acc += (k[di + 1] * k[dj + 1]) * v;
+        }
+    *reinterpret_cast<f32x4*>(y + pix * C + 4 * cq) = acc;
+}
+
+// planar rgb [nb,3,HW] (+)= W[3][K] net[pix][K] + b     (feat_2_rgb_list)
+__global__ void nrt_to_rgb_kernel(int nb, int HW, int K, const float* __restrict__ net, const float* __restrict__ Wt,
+                                  const float* __restrict__ bias, const float* __restrict__ rgb_in, float* __restrict__ rgb_out,
+                                  int final_sigmoid) {
+    extern __shared__ float wl[];
+    for (int i = threadIdx.x; i < 3 * K; i += blockDim.x) wl[i] = Wt[i];
+    __syncthreads();
+    size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (size_t)nb * HW) return;
+    const float* xr = net + pix * K;
+    float a0 = bias[0], a1 = bias[1], a2 = bias[2];
+    for (int k = 0; k < K; ++k) {
+        const float v = xr[k];
+        a0 = fmaf(wl[k], v, a0);
+        a1 = fmaf(wl[K + k], v, a1);
+        a2 = fmaf(wl[2 * K + k], v, a2);
+    }
+    size_t img = pix / HW, p = pix % HW, o = img * 3 * (size_t)HW + p;
+    if (rgb_in) {
+        a0 = rgb_in[o] + a0;
+        a1 = rgb_in[o + HW] + a1;
+        a2 = rgb_in[o + 2 * (size_t)HW] + a2;
+    }
+    if (final_sigmoid) {
+        a0 = 1.0f / (1.0f + expf(-a0));
+        a1 = 1.0f / (1.0f + expf(-a1));
+        a2 = 1.0f / (1.0f + expf(-a2));
+    }
+    rgb_out[o] = a0;
+    rgb_out[o + HW] = a1;
+    rgb_out[o + 2 * (size_t)HW] = a2;
+}
+
+__device__ __forceinline__ float nrt_bilinear_at(const float* __restrict__ x, int h, int w, int i, int j) {
+    float si = fmaxf(0.5f * ((float)i + 0.5f) - 0.5f, 0.0f);
+    float sj = fmaxf(0.5f * ((float)j + 0.5f) - 0.5f, 0.0f);
+    int i0 = (int)si, j0 = (int)sj;
+    int i1 = i0 + (i0 < h - 1 ? 1 : 0), j1 = j0 + (j0 < w - 1 ? 1 : 0);
+    float li = si - (float)i0, lj = sj - (float)j0;
+    return (1.0f - li) * ((1.0f - lj) * x[i0 * w + j0] + lj * x[i0 * w + j1]) + li * ((1.0f - lj) * x[i1 * w + j0] + lj * x[i1 * w + j1]);
+}
+
+__global__ void nrt_rgb_up_kernel(int n_planes, int h, int w, const float* __restrict__ x, float* __restrict__ y) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int H2 = 2 * h, W2 = 2 * w;
+    if (i >= (size_t)n_planes * H2 * W2) return;
+    int oj = (int)(i % W2), oi = (int)((i / W2) % H2);
+    size_t pl = i / ((size_t)W2 * H2);
+    const float* xp = x + pl * (size_t)h * w;
+    const float k[3] = {0.25f, 0.5f, 0.25f};
+    float acc = 0.0f;
+#pragma unroll
+    for (int di = -1; di <= 1; ++di)
+#pragma unroll
+        for (int dj = -1; dj <= 1; ++dj)
+            acc += (k[di + 1] * k[dj + 1]) * nrt_bilinear_at(xp, h, w, reflect1(oi + di, H2), reflect1(oj + dj, W2));
+    y[i] = acc;
+}
+
+// ---- backward pieces --------------------------------------------------------------------------
+// 1-D adjoint taps of the reflect-border [1,2,1]/4 blur: which outputs i read input j, with what weight
+__device__ __forceinline__ int blur_adj_taps(int j, int n, int idx[5], float wt[5]) {
+    int c = 0;
+    if (j - 1 >= 0) { idx[c] = j - 1; wt[c++] = 0.25f; }   // output j-1 reads j at d=+1
+    idx[c] = j; wt[c++] = 0.5f;
+    if (j + 1 < n) { idx[c] = j + 1; wt[c++] = 0.25f; }    // output j+1 reads j at d=-1
+    if (j == 1) { idx[c] = 0; wt[c++] = 0.25f; }           // output 0 reads reflect(-1) = 1
+    if (j == n - 2) { idx[c] = n - 1; wt[c++] = 0.25f; }   // output n-1 reads reflect(n) = n-2
+    return c;
+}
+
+__global__ void nrt_blur_adj_kernel(int nb, int H, int W, int C, const float* __restrict__ dy, float* __restrict__ dx) {
+    const int c4 = C / 4;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nb * H * W * c4) return;
+    int cq = (int)(i % c4);
+    size_t pix = i / c4;
+    int w = (int)(pix % W), h = (int)((pix / W) % H), img = (int)(pix / ((size_t)W * H));
+    int ih[5], iw[5];
+    float wh[5], ww[5];
+    const int nh = blur_adj_taps(h, H, ih, wh), nw = blur_adj_taps(w, W, iw, ww);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(dy + (((size_t)img * H + ih[a]) * W + iw[b]) * C + 4 * cq);
+            acc += (wh[a] * ww[b]) * v;
+        }
+    *reinterpret_cast<f32x4*>(dx + pix * C + 4 * cq) = acc;
+}
+
+// planar variant for the rgb pyramid (single channel planes)
+__global__ void nrt_blur_adj_planar_kernel(int n_planes, int H, int W, const float* __restrict__ dy, float* __restrict__ dx) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_planes * H * W) return;
+    int w = (int)(i % W), h = (int)((i / W) % H);
+    size_t pl = i / ((size_t)W * H);
+    int ih[5], iw[5];
+    float wh[5], ww[5];
+    const int nh = blur_adj_taps(h, H, ih, wh), nw = blur_adj_taps(w, W, iw, ww);
+    const float* d = dy + pl * (size_t)H * W;
+    float acc = 0.0f;
+    for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b) acc += (wh[a] * ww[b]) * d[(size_t)ih[a] * W + iw[b]];
+    dx[i] = acc;
+}
+
+// adjoint of the x2 bilinear upsample (align_corners=False): input m receives from outputs 2m-1..2m+2
+__device__ __forceinline__ int bil_adj_taps(int m, int n, int idx[4], float wt[4]) {
+    int c = 0;
+    idx[c] = 2 * m; wt[c++] = m == 0 ? 1.0f : 0.75f;             // even output 2m: (m-1: .25, m: .75), clamped at 0
+    idx[c] = 2 * m + 1; wt[c++] = m == n - 1 ? 1.0f : 0.75f;     // odd output 2m+1: (m: .75, m+1: .25), clamped at n-1
+    if (m + 1 < n) { idx[c] = 2 * m + 2; wt[c++] = 0.25f; }      // even output 2(m+1) reads m with .25
+    if (m >= 1) { idx[c] = 2 * m - 1; wt[c++] = 0.25f; }         // odd output 2(m-1)+1 reads m with .25
+    return c;
+}
+
+__global__ void nrt_bilinear_adj_kernel(int n_planes, int h, int w, const float* __restrict__ dy /*[2h][2w]*/, float* __restrict__ dx) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_planes * h * w) return;
+    int jw = (int)(i % w), jh = (int)((i / w) % h);
+    size_t pl = i / ((size_t)w * h);
+    int ih[4], iw[4];
+    float wh[4], ww[4];
+    const int nh = bil_adj_taps(jh, h, ih, wh), nw = bil_adj_taps(jw, w, iw, ww);
+    const float* d = dy + pl * (size_t)4 * h * w;
+    float acc = 0.0f;
+    for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b) acc += (wh[a] * ww[b]) * d[(size_t)ih[a] * 2 * w + iw[b]];
+    dx[i] = acc;
+}
+
+// d_pre = d_img * y (1 - y)
+__global__ void nrt_sigmoid_bwd_kernel(size_t n, const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dx[i] = dy[i] * y[i] * (1.0f - y[i]);
+}
+
+// dnet[pix][k] (+)= sum_c d_rgb[img][c][p] W[c][k], gated by lrelu'(net) when gate != nullptr
+__global__ void nrt_to_rgb_bwd_kernel(int nb, int HW, int K, const float* __restrict__ d_rgb, const float* __restrict__ Wt,
+                                      const float* __restrict__ gate, float* __restrict__ dnet, int accumulate) {
+    extern __shared__ float wl[];
+    for (int i = threadIdx.x; i < 3 * K; i += blockDim.x) wl[i] = Wt[i];
+    __syncthreads();
+    const int k4 = K / 4;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nb * HW * k4) return;
+    const int kq = (int)(i % k4);
+    const size_t pix = i / k4, img = pix / HW, p = pix % HW, o = img * 3 * (size_t)HW + p;
+    const float d0 = d_rgb[o], d1 = d_rgb[o + HW], d2 = d_rgb[o + 2 * (size_t)HW];
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = d0 * wl[4 * kq + j] + d1 * wl[K + 4 * kq + j] + d2 * wl[2 * K + 4 * kq + j];
+    float* dst = dnet + pix * K + 4 * kq;
+    if (gate) {
+        f32x4 y = *reinterpret_cast<const f32x4*>(gate + pix * K + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = y[j] > 0.0f ? v[j] : 0.2f * v[j];
+    }
+    if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+    *reinterpret_cast<f32x4*>(dst) = v;
+}
+
+// x *= lrelu'(gate)
+__global__ void nrt_gate_kernel(size_t n, const float* __restrict__ gate, float* __restrict__ x) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = gate[i] > 0.0f ? x[i] : 0.2f * x[i];
+}
+
+// pixel-shuffle + residual adjoint: dps [4M][C] -> dtv [M][4C] gated by lrelu'(tv), and dx_res[M][C] = sum over the 4 repeats
+__global__ void nrt_unshuffle_kernel(int nb, int H, int W, int C, const float* __restrict__ dps, const float* __restrict__ tv,
+                                     float* __restrict__ dtv, float* __restrict__ dxres) {
+    const size_t total = (size_t)nb * H * W * C;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cp = (int)(i % C);  // residual channel c' : receives every o with o % C == c'
+    const size_t m = i / C;
+    const int w = (int)(m % W), h = (int)((m / W) % H), img = (int)(m / ((size_t)W * H));
+    float res = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = r * C + cp;
+        const int c = o >> 2, di = (o >> 1) & 1, dj = o & 1;
+        const float d = dps[(((size_t)img * 2 * H + 2 * h + di) * 2 * W + 2 * w + dj) * C + c];
+        res += d;
+        const float y = tv[m * 4 * C + o];
+        dtv[m * 4 * C + o] = y > 0.0f ? d : 0.2f * d;
+    }
+    dxres[i] = res;
+}
+
+__global__ void nrt_add_kernel(size_t n, const float* __restrict__ a, float* __restrict__ x) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] += a[i];
+}
+
+// out[n] += sum_m X[m][n]
+__global__ void nrt_colsum_kernel(const float* __restrict__ X, long ldx, long rows, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    float acc = 0.0f;
+    for (long r = r0; r < r1; ++r) acc += X[r * ldx + n];
+    atomicAdd(&out[n], acc);
+}
+
+// db[c] += sum over images and pixels of planar d_rgb
+__global__ void nrt_rgb_bias_kernel(int nb, int HW, const float* __restrict__ d_rgb, float* __restrict__ db) {
+    __shared__ float red[256];
+    const int c = blockIdx.y;
+    float acc = 0.0f;
+    for (int img = 0; img < nb; ++img) {
+        const float* d = d_rgb + ((size_t)img * 3 + c) * HW;
+        for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < (size_t)HW; p += (size_t)gridDim.x * blockDim.x) acc += d[p];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(&db[c], red[0]);
+}
+
+#define GRID1(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256)
+
+static Gemm32 mk(int M, int N, int K, const float* A, long lda, int ak, const float* B, long ldb, int bk, float* C, long ldc) {
+    Gemm32 g;
+    g.M = M; g.N = N; g.K = K;
+    g.A = A; g.lda = lda; g.a_kmajor = ak;
+    g.B = B; g.ldb = ldb; g.b_kmajor = bk;
+    g.C = C; g.ldc = ldc;
+    g.bias = nullptr; g.bias_group_rows = 0; g.bias_ld = 0;
+    g.act = G32_ACT_NONE;
+    g.gate = nullptr; g.ldgate = 0; g.gate_act = G32_ACT_NONE;
+    g.accumulate = 0; g.split_k = 1;
+    return g;
+}
+static int split_for(long K);
+// parameter-gradient products always ADD into their destination: atomics when K is split, += otherwise
+static void set_grad_split(Gemm32& q, long K) {
+    q.split_k = split_for(K);
+    q.accumulate = q.split_k <= 1 ? 1 : 0;
+}
+static int split_for(long K) {
+    long s = K / 2048;
+    return (int)(s < 1 ? 1 : (s > 128 ? 128 : s));
+}
+
+// featmap [nb][fs*fs][C] -> img [nb,3,P,P]; all intermediates kept in `saved`
+extern "C" void n3dt_launch_nr_train_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap, float* img,
+                                         float* saved, float* ws, hipStream_t s) {
+    const NrSaved sv = nr_saved_layout(g, nb);
+    const NrWs wl = nr_ws_layout(g, nb);
+    const int C = g->feat_nc, nblk = g->n_blocks;
+    float* rgbA = ws + wl.rgb0;
+    float* rgbB = ws + wl.rgb1;
+    float* ps = ws + wl.a;
+    int h = g->featmap_size;
+    hipLaunchKernelGGL(nrt_to_rgb_kernel, GRID1((size_t)nb * h * h), 3 * C * sizeof(float), s, nb, h * h, C, featmap, p->to_rgb_w[0],
+                       p->to_rgb_b[0], (const float*)nullptr, rgbB, 0);
+    hipLaunchKernelGGL(nrt_rgb_up_kernel, GRID1((size_t)nb * 3 * 4 * h * h), 0, s, nb * 3, h, h, rgbB, rgbA);
+    const float* x = featmap;
+    for (int i = 0; i < nblk; ++i) {
+        const int ci = nr_ch(C, i), co = nr_ch(C, i + 1), M = nb * h * h;
+        Gemm32 q1 = mk(M, 2 * ci, ci, x, ci, 0, p->psu1_w[i], ci, 0, saved + sv.t1[i], 2 * ci);
+        q1.bias = p->psu1_b[i]; q1.act = G32_ACT_LRELU;
+        n3dt_gemm32(q1, s);
+        Gemm32 q2 = mk(M, 4 * ci, 2 * ci, saved + sv.t1[i], 2 * ci, 0, p->psu2_w[i], 2 * ci, 0, saved + sv.tv[i], 4 * ci);
+        q2.bias = p->psu2_b[i]; q2.act = G32_ACT_LRELU;
+        n3dt_gemm32(q2, s);
+        hipLaunchKernelGGL(nrt_shuffle_kernel, GRID1((size_t)M * 4 * ci), 0, s, nb, h, h, ci, saved + sv.tv[i], x, ps);
+        h *= 2;
+        hipLaunchKernelGGL(nrt_blur_kernel, GRID1((size_t)nb * h * h * (ci / 4)), 0, s, nb, h, h, ci, ps, saved + sv.bl[i]);
+        Gemm32 q3 = mk(nb * h * h, co, ci, saved + sv.bl[i], ci, 0, p->feat_w[i], ci, 0, saved + sv.net[i], co);
+        q3.bias = p->feat_b[i]; q3.act = G32_ACT_LRELU;
+        n3dt_gemm32(q3, s);
+        const bool last = i == nblk - 1;
+        hipLaunchKernelGGL(nrt_to_rgb_kernel, GRID1((size_t)nb * h * h), 3 * co * sizeof(float), s, nb, h * h, co, saved + sv.net[i],
+                           p->to_rgb_w[i + 1], p->to_rgb_b[i + 1], (const float*)rgbA, last ? saved + sv.img : rgbB, last ? 1 : 0);
+        if (!last) hipLaunchKernelGGL(nrt_rgb_up_kernel, GRID1((size_t)nb * 3 * 4 * h * h), 0, s, nb * 3, h, h, rgbB, rgbA);
+        x = saved + sv.net[i];
+    }
+    const size_t P = (size_t)g->featmap_size << nblk;
+    (void)hipMemcpyAsync(img, saved + sv.img, sizeof(float) * nb * 3 * P * P, hipMemcpyDeviceToDevice, s);
+}
+
+// gradients are ACCUMULATED into gp (same pointer layout as the parameters); d_featmap is overwritten
+extern "C" void n3dt_launch_nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N3dtRenderGrads* gp,
+                                   const float* featmap, const float* d_img, const float* saved, float* d_featmap, float* ws,
+                                   hipStream_t s) {
+    const NrSaved sv = nr_saved_layout(g, nb);
+    const NrWs wl = nr_ws_layout(g, nb);
+    const int C = g->feat_nc, nblk = g->n_blocks;
+    const size_t P = (size_t)g->featmap_size << nblk;
+    float* bufA = ws + wl.a;
+    float* bufB = ws + wl.b;
+    float* bufC = ws + wl.c;
+    float* drgb = ws + wl.rgb0;   // gradient w.r.t. the running rgb sum at the current resolution
+    float* dtmp = ws + wl.rgb1;
+    int h = (int)P;
+    hipLaunchKernelGGL(nrt_sigmoid_bwd_kernel, GRID1((size_t)nb * 3 * P * P), 0, s, (size_t)nb * 3 * P * P, saved + sv.img, d_img, drgb);
+    float* dnet = bufA;  // gradient w.r.t. net_i (stage output), [nb*h*h][co]
+    for (int i = nblk - 1; i >= 0; --i) {
+        const int ci = nr_ch(C, i), co = nr_ch(C, i + 1);
+        const int hin = h / 2, M = nb * hin * hin, M4 = nb * h * h, HW = h * h;
+        const float* x = i == 0 ? featmap : saved + sv.net[i - 1];
+        const float* net = saved + sv.net[i];
+        // rgb = rgb_prev_up + feat_2_rgb[i+1](net): parameter grads, then d net (gated by lrelu'(net))
+        for (int im = 0; im < nb; ++im) {
+            Gemm32 w = mk(3, co, HW, drgb + (size_t)im * 3 * HW, HW, 0, net + (size_t)im * HW * co, co, 1, gp->to_rgb_w[i + 1], co);
+            set_grad_split(w, HW);
+            n3dt_gemm32(w, s);
+        }
+        hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[i + 1]);
+        // d net: from the rgb branch (+ from the next stage's input gradient, already in dnet when i < nblk-1)
+        if (i == nblk - 1) {
+            hipLaunchKernelGGL(nrt_to_rgb_bwd_kernel, GRID1((size_t)M4 * (co / 4)), 3 * co * sizeof(float), s, nb, HW, co, drgb,
+                               p->to_rgb_w[i + 1], net, dnet, 0);
+        } else {
+            // dnet currently holds dL/d(net) from stage i+1 (ungated); add the rgb branch, then gate once
+            hipLaunchKernelGGL(nrt_to_rgb_bwd_kernel, GRID1((size_t)M4 * (co / 4)), 3 * co * sizeof(float), s, nb, HW, co, drgb,
+                               p->to_rgb_w[i + 1], (const float*)nullptr, dnet, 1);
+            hipLaunchKernelGGL(nrt_gate_kernel, GRID1((size_t)M4 * co), 0, s, (size_t)M4 * co, net, dnet);
+        }
+        // feat conv: net = lrelu(bl Wf^T + bf)
+        {
+            Gemm32 w = mk(co, ci, M4, dnet, co, 1, saved + sv.bl[i], ci, 1, gp->feat_w[i], ci);
+            set_grad_split(w, M4);
+            n3dt_gemm32(w, s);
+            hipLaunchKernelGGL(nrt_colsum_kernel, dim3((co + 255) / 256, 256), dim3(256), 0, s, dnet, (long)co, (long)M4, co, gp->feat_b[i]);
+            Gemm32 q = mk(M4, ci, co, dnet, co, 0, p->feat_w[i], ci, 1, bufB, ci);  // d bl
+            n3dt_gemm32(q, s);
+        }
+        // blur adjoint -> d ps (bufC), then un-shuffle into d tv (bufB, gated) and the residual gradient (bufA)
+        hipLaunchKernelGGL(nrt_blur_adj_kernel, GRID1((size_t)M4 * (ci / 4)), 0, s, nb, h, h, ci, bufB, bufC);
+        hipLaunchKernelGGL(nrt_unshuffle_kernel, GRID1((size_t)M * ci), 0, s, nb, hin, hin, ci, bufC, saved + sv.tv[i], bufB, bufA);
+        float* dtv = bufB;    // [M][4ci]
+        float* dxres = bufA;  // [M][ci]
+        // layer_2: tv = lrelu(t1 W2^T + b2)
+        {
+            Gemm32 w = mk(4 * ci, 2 * ci, M, dtv, 4 * ci, 1, saved + sv.t1[i], 2 * ci, 1, gp->psu2_w[i], 2 * ci);
+            set_grad_split(w, M);
+            n3dt_gemm32(w, s);
+            hipLaunchKernelGGL(nrt_colsum_kernel, dim3((4 * ci + 255) / 256, 128), dim3(256), 0, s, dtv, (long)4 * ci, (long)M, 4 * ci,
+                               gp->psu2_b[i]);
+            Gemm32 q = mk(M, 2 * ci, 4 * ci, dtv, 4 * ci, 0, p->psu2_w[i], 2 * ci, 1, bufC, 2 * ci);  // d t1, gated by lrelu'(t1)
+            q.gate = saved + sv.t1[i]; q.ldgate = 2 * ci; q.gate_act = G32_ACT_LRELU;
+            n3dt_gemm32(q, s);
+        }
+        // layer_1: t1 = lrelu(x W1^T + b1);  dx = dt1 W1 + residual gradient
+        {
+            Gemm32 w = mk(2 * ci, ci, M, bufC, 2 * ci, 1, x, ci, 1, gp->psu1_w[i], ci);
+            set_grad_split(w, M);
+            n3dt_gemm32(w, s);
+            hipLaunchKernelGGL(nrt_colsum_kernel, dim3((2 * ci + 255) / 256, 128), dim3(256), 0, s, bufC, (long)2 * ci, (long)M, 2 * ci,
+                               gp->psu1_b[i]);
+            Gemm32 q = mk(M, ci, 2 * ci, bufC, 2 * ci, 0, p->psu1_w[i], ci, 1, dxres, ci);
+            q.accumulate = 1;
+            n3dt_gemm32(q, s);
+        }
+        // rgb pyramid: at stage i > 0 the running rgb came from rgb_upsample of the previous sum
+        h = hin;
+        if (i > 0) {
+            hipLaunchKernelGGL(nrt_blur_adj_planar_kernel, GRID1((size_t)nb * 3 * 4 * h * h), 0, s, nb * 3, 2 * h, 2 * h, drgb, dtmp);
+            hipLaunchKernelGGL(nrt_bilinear_adj_kernel, GRID1((size_t)nb * 3 * h * h), 0, s, nb * 3, h, h, dtmp, drgb);
+        }
+        dnet = dxres;  // = dL/d(x_i) = dL/d(net_{i-1}) (ungated) for the next iteration; lives in bufA
+    }
+    // stage-0 rgb: rgb_upsample(feat_2_rgb_list[0](featmap))
+    {
+        const int fs = g->featmap_size, HW = fs * fs;
+        hipLaunchKernelGGL(nrt_blur_adj_planar_kernel, GRID1((size_t)nb * 3 * 4 * HW), 0, s, nb * 3, 2 * fs, 2 * fs, drgb, dtmp);
+        hipLaunchKernelGGL(nrt_bilinear_adj_kernel, GRID1((size_t)nb * 3 * HW), 0, s, nb * 3, fs, fs, dtmp, drgb);
+        for (int im = 0; im < nb; ++im) {
+            Gemm32 w = mk(3, C, HW, drgb + (size_t)im * 3 * HW, HW, 0, featmap + (size_t)im * HW * C, C, 1, gp->to_rgb_w[0], C);
+            set_grad_split(w, HW);
+            n3dt_gemm32(w, s);
+        }
+        hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[0]);
+        hipLaunchKernelGGL(nrt_to_rgb_bwd_kernel, GRID1((size_t)nb * HW * (C / 4)), 3 * C * sizeof(float), s, nb, HW, C, drgb,
+                           p->to_rgb_w[0], (const float*)nullptr, dnet, 1);
+        (void)hipMemcpyAsync(d_featmap, dnet, sizeof(float) * (size_t)nb * HW * C, hipMemcpyDeviceToDevice, s);
+    }
+}

@@ -45,6 +45,9 @@ EXPORTS = [
     "n3dt_abi_version", "n3dt_last_error", "n3dt_mlp_packed_bytes", "n3dt_mlp_pack",
     "n3dt_render_workspace_bytes", "n3dt_render_fwd", "n3dt_neural_render_workspace_bytes",
     "n3dt_neural_render_fwd", "n3dt_chw_to_hwc", "n3dt_prof_enable", "n3dt_prof_collect",
+    "n3dt_render_train_saved_bytes", "n3dt_render_train_workspace_bytes", "n3dt_render_train_fwd", "n3dt_render_bwd",
+    "n3dt_neural_render_train_saved_bytes", "n3dt_neural_render_train_workspace_bytes",
+    "n3dt_neural_render_train_fwd", "n3dt_neural_render_bwd",
 ]
 
 _LIB = None
@@ -79,6 +82,23 @@ def lib():
     L.n3dt_neural_render_fwd.argtypes = [ctypes.POINTER(Geom), ci, ci, ctypes.POINTER(RenderParams), vp, vp, vp, sz, vp]
     L.n3dt_chw_to_hwc.restype = ci
     L.n3dt_chw_to_hwc.argtypes = [ci, ci, vp, vp, vp]
+    gp, mp, rp = ctypes.POINTER(Geom), ctypes.POINTER(MlpParams), ctypes.POINTER(RenderParams)
+    L.n3dt_render_train_saved_bytes.restype = sz
+    L.n3dt_render_train_saved_bytes.argtypes = [gp]
+    L.n3dt_render_train_workspace_bytes.restype = sz
+    L.n3dt_render_train_workspace_bytes.argtypes = [gp]
+    L.n3dt_render_train_fwd.restype = ci
+    L.n3dt_render_train_fwd.argtypes = [gp, vp, mp] + [vp] * 13 + [vp, sz, vp, sz, vp]
+    L.n3dt_render_bwd.restype = ci
+    L.n3dt_render_bwd.argtypes = [gp, mp, mp] + [vp] * 7 + [vp, sz] + [vp] * 4 + [vp, sz, vp]
+    L.n3dt_neural_render_train_saved_bytes.restype = sz
+    L.n3dt_neural_render_train_saved_bytes.argtypes = [gp, ci]
+    L.n3dt_neural_render_train_workspace_bytes.restype = sz
+    L.n3dt_neural_render_train_workspace_bytes.argtypes = [gp, ci]
+    L.n3dt_neural_render_train_fwd.restype = ci
+    L.n3dt_neural_render_train_fwd.argtypes = [gp, ci, rp, vp, vp, vp, sz, vp, sz, vp]
+    L.n3dt_neural_render_bwd.restype = ci
+    L.n3dt_neural_render_bwd.argtypes = [gp, ci, rp, rp, vp, vp, vp, sz, vp, vp, sz, vp]
     L.n3dt_prof_enable.restype = ci
     L.n3dt_prof_enable.argtypes = [ci]
     L.n3dt_prof_collect.restype = ci

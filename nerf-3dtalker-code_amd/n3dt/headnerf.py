@@ -130,6 +130,24 @@ class NeuralRenderer(nn.Module):
         return ops.render_params([wb(m) for m in self.feat_2_rgb_list], [wb(m.layer_1) for m in self.feat_upsample_list],
                                  [wb(m.layer_2) for m in self.feat_upsample_list], [wb(m) for m in self.feat_layers])
 
+    def _flat_modules(self):
+        """(weight, bias) holders in the order of _rparams_from: to_rgb[0..n], psu1[0..n-1], psu2[0..n-1], feat[0..n-1]"""
+        return (list(self.feat_2_rgb_list) + [m.layer_1 for m in self.feat_upsample_list] +
+                [m.layer_2 for m in self.feat_upsample_list] + list(self.feat_layers))
+
+    def _rparams_from(self, tensors):
+        """tensors: [w, b] pairs flattened in _flat_modules() order (2-D weights)"""
+        n = self.n_blocks
+        pairs = [(tensors[2 * i], tensors[2 * i + 1]) for i in range(len(tensors) // 2)]
+        return ops.render_params(pairs[:n + 1], pairs[n + 1:2 * n + 1], pairs[2 * n + 1:3 * n + 1], pairs[3 * n + 1:])
+
+    def render_hwc_train(self, featmap_hwc):
+        """Differentiable [nb, fs, fs, C] -> [nb, 3, P, P] (exact fp32)."""
+        flat = []
+        for m in self._flat_modules():
+            flat += [m.weight, m.bias]
+        return _NeuralRenderFn.apply(self, featmap_hwc, *flat)
+
     def render_hwc(self, featmap_hwc, precision="fp32"):
         """[nb, fs, fs, C] ray-major feature maps -> [nb, 3, P, P]"""
         nb = featmap_hwc.shape[0]
@@ -137,11 +155,70 @@ class NeuralRenderer(nn.Module):
 
     def forward(self, x):
         """x: [nb, C, fs, fs] like the reference module."""
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("NeuralRenderer backward is not built yet; call under torch.no_grad()")
         nb, C, fs, _ = x.shape
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self.render_hwc_train(x.permute(0, 2, 3, 1).contiguous())
         hwc = torch.stack([ops.chw_to_hwc(x[i].contiguous(), C, fs * fs) for i in range(nb)]).view(nb, fs, fs, C)
         return self.render_hwc(hwc)
+
+
+
+class _RenderFn(torch.autograd.Function):
+    """a1..a7 with saved activations (n3dt_render_train_fwd) and its backward (n3dt_render_bwd).
+    Inputs after `net`/`geom`: xy, R, T, Kinv, t_rand (no grad), then shape, appea, audio, bg_featmap and the
+    24 MLP parameter tensors (all differentiable).  Camera gradients are not built yet."""
+
+    @staticmethod
+    def forward(ctx, net, geom, xy, R, T, Kinv, t_rand, shape, appea, audio, bg_featmap, *mlp):
+        ws = [t.detach().view(t.shape[0], -1).contiguous() for t in mlp[:12]]
+        bs = [t.detach().contiguous() for t in mlp[12:]]
+        params = ops.mlp_params(ws, bs)
+        packed = net._packed(geom, _lib.F32, params, ws, bs)
+        shape_c, appea_c = ops._f32c(shape), ops._f32c(appea)
+        audio_c = ops._f32c(audio) if geom.audio_dim > 0 else None
+        bg = bg_featmap.detach().reshape(geom.feat_nc, -1).contiguous()
+        out, saved = ops.render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape_c, appea_c, audio_c, t_rand, bg)
+        ctx.geom, ctx.saved, ctx.keep = geom, saved, (ws, bs, shape_c, appea_c, audio_c, bg)
+        ctx.bg_shape = bg_featmap.shape
+        ctx.mlp_shapes = [t.shape for t in mlp]
+        return out["merge_feat"]
+
+    @staticmethod
+    def backward(ctx, d_merge):
+        ws, bs, shape_c, appea_c, audio_c, bg = ctx.keep
+        geom = ctx.geom
+        gws = [torch.zeros_like(w) for w in ws]
+        gbs = [torch.zeros_like(b) for b in bs]
+        d_bg, d_shape, d_appea, d_audio = ops.render_bwd(geom, ops.mlp_params(ws, bs), ops.mlp_params(gws, gbs), shape_c, appea_c,
+                                                         audio_c, bg, d_merge.contiguous(), ctx.saved)
+        ctx.saved = None
+        grads = [g.view(s) for g, s in zip(gws + gbs, ctx.mlp_shapes)]
+        return (None, None, None, None, None, None, None, d_shape, d_appea, d_audio, d_bg.view(ctx.bg_shape), *grads)
+
+
+class _NeuralRenderFn(torch.autograd.Function):
+    """a8..a10 with saved activations and the hand-written backward (n3dt_neural_render_bwd)."""
+
+    @staticmethod
+    def forward(ctx, nr, featmap, *flat):
+        nb = featmap.shape[0]
+        geom = nr._geom(nb)
+        tensors = [t.detach().view(t.shape[0], -1).contiguous() if t.dim() == 4 else t.detach().contiguous() for t in flat]
+        rp = nr._rparams_from(tensors)
+        fm = featmap.detach().contiguous()
+        img, saved = ops.neural_render_train_fwd(geom, nb, rp, fm)
+        ctx.nr, ctx.geom, ctx.nb, ctx.saved, ctx.keep = nr, geom, nb, saved, (tensors, fm)
+        ctx.shapes = [t.shape for t in flat]
+        return img
+
+    @staticmethod
+    def backward(ctx, d_img):
+        tensors, fm = ctx.keep
+        gt = [torch.zeros_like(t) for t in tensors]
+        d_feat = ops.neural_render_bwd(ctx.geom, ctx.nb, ctx.nr._rparams_from(tensors), ctx.nr._rparams_from(gt), fm,
+                                       d_img.contiguous(), ctx.saved)
+        ctx.saved = None
+        return (None, d_feat, *[g.view(s) for g, s in zip(gt, ctx.shapes)])
 
 
 class _Seam(nn.Module):
@@ -250,22 +327,43 @@ class HeadNeRFNet(nn.Module):
         if n_r != self.featmap_size ** 2:
             raise ValueError("forward() renders an image, so N_r must equal featmap_size^2; "
                              "use render_features() for free ray sets")
-        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
-                                        any(torch.is_tensor(t) and t.requires_grad for t in
-                                            (audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs))):
-            raise NotImplementedError("the backward kernels are not built yet; call under torch.no_grad()")
         if for_train and t_rand is None:
             # same generator consumption as the reference's torch.rand_like(zvals) (NetWorks/utils.py:77)
             t_rand = torch.rand(batch_size, n_r, self.num_sample_coarse + 1, device=batch_xy.device, dtype=torch.float32)
+        fs, C = self.featmap_size, self.featmap_nc
+        needs_grad = torch.is_grad_enabled() and (
+            any(p.requires_grad for p in self.parameters()) or
+            any(torch.is_tensor(t) and t.requires_grad for t in (audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs)))
+        if needs_grad:
+            return self._forward_train(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand)
         out = self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
                                    t_rand=t_rand, want_merge=True)
-        fs, C = self.featmap_size, self.featmap_nc
         # the merged maps and the background map go through the 2-D renderer in one call (nb = B+1)
         maps = torch.empty(batch_size + 1, fs, fs, C, dtype=torch.float32, device=batch_xy.device)
         maps[:batch_size] = out["merge_feat"].view(batch_size, fs, fs, C)
         ops.chw_to_hwc(self.neural_render.bg_featmap.detach().view(C, fs * fs), C, fs * fs, maps[batch_size].view(fs * fs, C))
         imgs = self.neural_render.render_hwc(maps, self.precision)
         return {"coarse_dict": {"merge_img": imgs[:batch_size], "bg_img": imgs[batch_size:]}}
+
+    def _forward_train(self, batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand):
+        """Differentiable forward (exact fp32): gradients reach every parameter, audiostyle, shape_code, appea_code."""
+        for t, name in ((batch_Rmats, "batch_Rmats"), (batch_Tvecs, "batch_Tvecs")):
+            if torch.is_tensor(t) and t.requires_grad:
+                raise NotImplementedError("gradients w.r.t. %s (camera fitting, SURVEY 8f-1) are not built yet" % name)
+        B, _, n_r = batch_xy.size()
+        fs, C = self.featmap_size, self.featmap_nc
+        xy = batch_xy if batch_xy.dtype == torch.float32 else batch_xy.float()
+        geom = self._geom(B, n_r, xy)
+        layers = self.fg_CD_predictor.layers()
+        mlp = [m.weight for m in layers] + [m.bias for m in layers]
+        audio = audiostyle if self.audio_dim > 0 else torch.zeros(B, 0, device=xy.device)
+        merge = _RenderFn.apply(self, geom, xy.detach(), ops._f32c(batch_Rmats), ops._f32c(batch_Tvecs).view(B, 3),
+                                ops._f32c(batch_inv_inmats), None if t_rand is None else ops._f32c(t_rand),
+                                shape_code, appea_code, audio, self.neural_render.bg_featmap, *mlp)
+        bg_hwc = self.neural_render.bg_featmap.view(C, fs * fs).t().reshape(1, fs, fs, C)
+        maps = torch.cat([merge.view(B, fs, fs, C), bg_hwc], dim=0)
+        imgs = self.neural_render.render_hwc_train(maps)
+        return {"coarse_dict": {"merge_img": imgs[:B], "bg_img": imgs[B:]}}
 
     def forward(self, mode, batch_xy, batch_uv, audiostyle=None, bg_code=None, shape_code=None, appea_code=None,
                 batch_Rmats=None, batch_Tvecs=None, batch_inv_inmats=None, dist_expr=False, **kwargs):

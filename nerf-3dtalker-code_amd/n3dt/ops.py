@@ -137,3 +137,72 @@ def chw_to_hwc(src, C, n, dst=None):
         dst = torch.empty(n, C, dtype=torch.float32, device=src.device)
     check(lib().n3dt_chw_to_hwc(C, n, _ptr(src), _ptr(dst), _stream()), "n3dt_chw_to_hwc")
     return dst
+
+
+# ---- training path -------------------------------------------------------------------------------
+def _bytes_or_raise(n, what):
+    if n == 0:
+        raise _lib.N3dtError(what + ": " + lib().n3dt_last_error().decode())
+    return n
+
+
+def render_train_fwd(geom, packed_f32, params, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap):
+    """Forward with saved activations.  Returns (out dict, saved buffer)."""
+    dev = xy.device
+    B, Nr, C = geom.batch, geom.n_rays, geom.feat_nc
+    out = {
+        "fg_feat": torch.empty(B, Nr, C, dtype=torch.float32, device=dev),
+        "bg_alpha": torch.empty(B, Nr, dtype=torch.float32, device=dev),
+        "merge_feat": torch.empty(B, Nr, C, dtype=torch.float32, device=dev),
+    }
+    sbytes = _bytes_or_raise(lib().n3dt_render_train_saved_bytes(ctypes.byref(geom)), "n3dt_render_train_saved_bytes")
+    wbytes = _bytes_or_raise(lib().n3dt_render_train_workspace_bytes(ctypes.byref(geom)), "n3dt_render_train_workspace_bytes")
+    saved = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+    ws = WORKSPACE.get("train", wbytes, dev)
+    check(lib().n3dt_render_train_fwd(
+        ctypes.byref(geom), _ptr(packed_f32), ctypes.byref(params), _ptr(xy), _ptr(R), _ptr(T), _ptr(Kinv), _ptr(shape), _ptr(appea),
+        _ptr(audio), _ptr(t_rand), _ptr(bg_featmap), _ptr(out["fg_feat"]), _ptr(out["bg_alpha"]), None, _ptr(out["merge_feat"]),
+        _ptr(saved), sbytes, _ptr(ws), wbytes, _stream()), "n3dt_render_train_fwd")
+    return out, saved
+
+
+def render_bwd(geom, params, grads, shape, appea, audio, bg_featmap, d_merge, saved):
+    """Backward of render_train_fwd.  `grads` (MlpParams struct of zeroed tensors) is accumulated into.
+    Returns (d_bg_featmap [C,Nr], d_shape, d_appea, d_audio)."""
+    dev = d_merge.device
+    B, Nr, C = geom.batch, geom.n_rays, geom.feat_nc
+    d_bg = torch.zeros(C, Nr, dtype=torch.float32, device=dev)
+    d_shape = torch.empty(B, geom.shape_dim, dtype=torch.float32, device=dev)
+    d_appea = torch.empty(B, geom.appea_dim, dtype=torch.float32, device=dev)
+    d_audio = torch.empty(B, geom.audio_dim, dtype=torch.float32, device=dev) if geom.audio_dim > 0 else None
+    wbytes = lib().n3dt_render_train_workspace_bytes(ctypes.byref(geom))
+    ws = WORKSPACE.get("train", wbytes, dev)
+    check(lib().n3dt_render_bwd(
+        ctypes.byref(geom), ctypes.byref(params), ctypes.byref(grads), _ptr(shape), _ptr(appea), _ptr(audio), _ptr(bg_featmap),
+        _ptr(d_merge), None, None, _ptr(saved), saved.numel(), _ptr(d_bg), _ptr(d_shape), _ptr(d_appea), _ptr(d_audio),
+        _ptr(ws), wbytes, _stream()), "n3dt_render_bwd")
+    return d_bg, d_shape, d_appea, d_audio
+
+
+def neural_render_train_fwd(geom, nb, rparams, featmap):
+    dev = featmap.device
+    P = geom.featmap_size << geom.n_blocks
+    img = torch.empty(nb, 3, P, P, dtype=torch.float32, device=dev)
+    sbytes = _bytes_or_raise(lib().n3dt_neural_render_train_saved_bytes(ctypes.byref(geom), nb), "n3dt_neural_render_train_saved_bytes")
+    wbytes = _bytes_or_raise(lib().n3dt_neural_render_train_workspace_bytes(ctypes.byref(geom), nb),
+                             "n3dt_neural_render_train_workspace_bytes")
+    saved = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+    ws = WORKSPACE.get("nr_train", wbytes, dev)
+    check(lib().n3dt_neural_render_train_fwd(ctypes.byref(geom), nb, ctypes.byref(rparams), _ptr(featmap), _ptr(img), _ptr(saved), sbytes,
+                                             _ptr(ws), wbytes, _stream()), "n3dt_neural_render_train_fwd")
+    return img, saved
+
+
+def neural_render_bwd(geom, nb, rparams, rgrads, featmap, d_img, saved):
+    dev = featmap.device
+    d_feat = torch.empty_like(featmap)
+    wbytes = lib().n3dt_neural_render_train_workspace_bytes(ctypes.byref(geom), nb)
+    ws = WORKSPACE.get("nr_train", wbytes, dev)
+    check(lib().n3dt_neural_render_bwd(ctypes.byref(geom), nb, ctypes.byref(rparams), ctypes.byref(rgrads), _ptr(featmap), _ptr(d_img),
+                                       _ptr(saved), saved.numel(), _ptr(d_feat), _ptr(ws), wbytes, _stream()), "n3dt_neural_render_bwd")
+    return d_feat

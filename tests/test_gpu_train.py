@@ -1,0 +1,127 @@
+"""Training path on the GPU: gradients and one optimizer step against the vectors the
+reference's own autograd produced (tests/golden/tiny_*.npz).  Exact-fp32 kernels.
+
+Tolerances: loss terms 1e-6 absolute.  Gradients: a ReLU gate sitting within float rounding of zero can
+flip between two correct fp32 evaluations of the forward (the positional encoding multiplies point
+coordinates by 512, so one ulp there is visible); one flipped gate moves a handful of sampled entries by
+~1e-3 of the tensor's scale.  Hence per-entry error <= 2e-2 * max|ref| and sum error <= 1e-3 * sum|ref|.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, synthetic_case
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def setup(name):
+    from n3dt import HeadNeRFNet, synthetic as syn
+    g, m = load_golden(name)
+    opt, sd, inp = synthetic_case(m)
+    net = HeadNeRFNet(opt, include_vd=False, hier_sampling=False).to(dev())
+    net.load_state_dict(sd, strict=True)
+    d = {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    t_rand = None
+    if m["mode"] == "train":
+        t_rand = syn.stratified_noise(m["batch"], opt.featmap_size ** 2, opt.num_sample_coarse, m["t_rand_seed"]).to(dev())
+    return g, m, opt, net, d, t_rand
+
+
+def run_loss(net, m, opt, d, t_rand):
+    from n3dt.train import data_losses, disk_mask
+    out = net(m["mode"], d["batch_xy"], d["batch_uv"], d["audiostyle"], bg_code=None, shape_code=d["shape_code"],
+              appea_code=d["appea_code"], batch_Rmats=d["batch_Rmats"], batch_Tvecs=d["batch_Tvecs"],
+              batch_inv_inmats=d["batch_inv_inmats"], t_rand=t_rand)["coarse_dict"]
+    gt = torch.full_like(out["merge_img"], 0.5)
+    mask = disk_mask(m["batch"], opt.pred_img_size).to(dev())
+    terms = data_losses(out, gt, mask)
+    return out, terms, terms["bg_loss"] + terms["head_loss"] + terms["nonhead_loss"]
+
+
+@pytest.mark.parametrize("name", ["tiny_test", "tiny_train"])
+def test_gradients_match_reference_autograd(name):
+    g, m, opt, net, d, t_rand = setup(name)
+    for k in ("audiostyle", "shape_code", "appea_code"):
+        d[k] = d[k].clone().requires_grad_(True)
+    out, terms, total = run_loss(net, m, opt, d, t_rand)
+    np.testing.assert_allclose([float(terms[k].detach()) for k in ("bg_loss", "head_loss", "nonhead_loss")], g["loss_terms"], atol=1e-6)
+    assert np.abs(out["merge_img"].detach().cpu().numpy() - g["merge_img"]).max() <= 1e-5
+    total.backward()
+    for k in ("audiostyle", "shape_code", "appea_code"):
+        ref = g["grad_in." + k]
+        assert np.abs(d[k].grad.cpu().numpy() - ref).max() <= 2e-2 * np.abs(ref).max(), k
+    for pname, p in net.named_parameters():
+        assert p.grad is not None, pname
+        idx, val = g["grad_p.%s.idx" % pname], g["grad_p.%s.val" % pname]
+        got = p.grad.reshape(-1)[torch.from_numpy(idx).to(dev())].cpu().numpy()
+        assert np.abs(got - val).max() <= 2e-2 * (np.abs(val).max() + 1e-12), pname
+        asum = float(g["grad_p.%s.abs" % pname])
+        assert abs(float(p.grad.double().sum()) - float(g["grad_p.%s.sum" % pname])) <= 1e-3 * asum + 1e-9, pname
+
+
+def test_one_adam_step_matches_reference():
+    """talker_trainer.py:722-723,1063-1067: zero_grad, backward, Adam(lr=1e-4).step()."""
+    from n3dt.train import make_optimizer
+    g, m, opt, net, d, t_rand = setup("tiny_train")
+    optim, _sched = make_optimizer(net, lr=1e-4)
+    _, _, total = run_loss(net, m, opt, d, t_rand)
+    optim.zero_grad()
+    total.backward()
+    optim.step()
+    close, n = 0, 0
+    for pname, p in net.named_parameters():
+        idx = torch.from_numpy(g["grad_p.%s.idx" % pname]).to(dev())
+        got = p.detach().reshape(-1)[idx].cpu().numpy()
+        ref = g["adam_p.%s.val" % pname]
+        # Adam's first step is lr*sign(g) (|g| >> eps): entries differ only where a gradient is ~0
+        assert np.abs(got - ref).max() <= 2.1e-4, pname
+        close += int((np.abs(got - ref) <= 1e-6).sum())
+        n += got.size
+    assert close >= 0.995 * n
+
+
+def test_train_path_forward_equals_inference_path():
+    g, m, opt, net, d, t_rand = setup("tiny_train")
+    out_t, _, _ = run_loss(net, m, opt, d, t_rand)
+    with torch.no_grad():
+        out_i, _, _ = run_loss(net, m, opt, d, t_rand)
+    assert float((out_t["merge_img"] - out_i["merge_img"]).abs().max()) <= 1e-5
+    assert float((out_t["bg_img"] - out_i["bg_img"]).abs().max()) <= 1e-6
+
+
+def test_gradients_accumulate_and_are_deterministic_enough():
+    g, m, opt, net, d, t_rand = setup("tiny_test")
+    _, _, total = run_loss(net, m, opt, d, t_rand)
+    total.backward()
+    g1 = {n: p.grad.clone() for n, p in net.named_parameters()}
+    _, _, total = run_loss(net, m, opt, d, t_rand)
+    total.backward()  # accumulates into .grad
+    for n, p in net.named_parameters():
+        scale = float(g1[n].abs().max()) + 1e-12
+        assert float((p.grad - 2 * g1[n]).abs().max()) <= 1e-4 * scale, n  # fp32 atomics: order-dependent last bits only
+
+
+def test_camera_gradients_refuse_loudly():
+    g, m, opt, net, d, t_rand = setup("tiny_test")
+    d["batch_Rmats"] = d["batch_Rmats"].clone().requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        run_loss(net, m, opt, d, t_rand)
+
+
+def test_loss_decreases_over_a_few_steps():
+    """fwd -> loss -> backward -> Adam, 5 steps at a larger lr: the harness trains."""
+    from n3dt.train import train_step, disk_mask
+    g, m, opt, net, d, t_rand = setup("tiny_train")
+    optim = torch.optim.Adam(net.parameters(), lr=2e-3)
+    gt = torch.full((m["batch"], 3, opt.pred_img_size, opt.pred_img_size), 0.5, device=dev())
+    mask = disk_mask(m["batch"], opt.pred_img_size).to(dev())
+    losses = []
+    for _ in range(5):
+        _, terms = train_step(net, optim, d, gt, mask, t_rand=t_rand)
+        losses.append(float(terms["total_loss"].detach()))
+    assert losses[-1] < losses[0]

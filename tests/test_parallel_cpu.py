@@ -1,0 +1,82 @@
+"""N > 1 path on CPU: two gloo ranks shard frames and average gradients through the flat-buffer all-reduce;
+the result must equal the single-process gradient of the full batch (loss is a mean over frames)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(3)
+    return torch.nn.Sequential(torch.nn.Linear(12, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+
+
+def _worker(rank, world, port, total_frames, out):
+    from n3dt import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _model()
+    if rank != 0:  # perturb, then check broadcast restores rank 0's weights
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+    parallel.broadcast_parameters(net)
+    torch.manual_seed(0)
+    x = torch.randn(total_frames, 12)
+    y = torch.randn(total_frames, 4)
+    lo, hi = parallel.shard_range(total_frames, rank, world)
+    loss = ((net(x[lo:hi]) - y[lo:hi]) ** 2).mean()
+    loss.backward()
+    parallel.allreduce_gradients(net.parameters())
+    if rank == 0:
+        out.put([p.grad.clone() for p in net.parameters()])
+    # the timing protocol of bench.py: barrier, then MAX of the per-rank elapsed time
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.barrier()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert float(t) == float(world)
+    dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    from n3dt import parallel
+    for total in (1, 7, 8, 32, 33):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                lo, hi = parallel.shard_range(total, r, world)
+                seen += list(range(lo, hi))
+            assert seen == list(range(total))
+
+
+def test_two_rank_gradient_average_equals_full_batch():
+    world, total = 2, 8  # equal shards: mean of shard means == full-batch mean
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    net = _model()
+    torch.manual_seed(0)
+    x = torch.randn(total, 12)
+    y = torch.randn(total, 4)
+    ((net(x) - y) ** 2).mean().backward()
+    for a, p in zip(got, net.parameters()):
+        torch.testing.assert_close(a, p.grad, rtol=1e-5, atol=1e-6)
