@@ -22,9 +22,6 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef X16_PREFETCH
-#define X16_PREFETCH 1
-#endif
 #define X16_BS 32
 #define X16_CH 24                      // pieces per chunk (24 KiB)
 #define X16_PIECE 1024                 // bytes
@@ -48,10 +45,31 @@ struct X16<N3DT_BF16> {
     }
     // ReLU on the packed 16-bit values: a signed 16-bit max with 0 (v_pk_max_i16) clears exactly
     // the negative floats, and rounding commutes with it
-    static __device__ __forceinline__ frag relu(frag f) {
+    // `lo` = 0: ReLU;  lo = -32768 (the most negative 16-bit pattern): identity -- lets one rolled loop body serve
+    // both the ReLU layers and the linear RGB_layer_0
+    static __device__ __forceinline__ frag relu(frag f, short lo) {
         s16x8 s = __builtin_bit_cast(s16x8, f);
-        s = __builtin_elementwise_max(s, (s16x8)(0));
+        s = __builtin_elementwise_max(s, (s16x8)(lo));
         return __builtin_bit_cast(frag, s);
+    }
+    // bias as an MFMA: A = [b_hi, b_lo, 0...] on the k = 0, 1 slots (lanes of the lower half), B = [1, 1, 0...]
+    static __device__ __forceinline__ frag bias_frag(float b, bool lower_half) {
+        __bf16 hi = (__bf16)b;
+        __bf16 lo = (__bf16)(b - (float)hi);
+        frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.0f;
+        if (lower_half) {
+            f[0] = hi;
+            f[1] = lo;
+        }
+        return f;
+    }
+    static __device__ __forceinline__ frag ones_frag() {
+        frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (__bf16)(j < 2 ? 1.0f : 0.0f);
+        return f;
     }
 };
 template <>
@@ -66,37 +84,131 @@ struct X16<N3DT_F16> {
         for (int j = 0; j < 8; ++j) f[j] = (_Float16)v[j];
         return f;
     }
-    static __device__ __forceinline__ frag relu(frag f) {
+    // `lo` = 0: ReLU;  lo = -32768 (the most negative 16-bit pattern): identity -- lets one rolled loop body serve
+    // both the ReLU layers and the linear RGB_layer_0
+    static __device__ __forceinline__ frag relu(frag f, short lo) {
         s16x8 s = __builtin_bit_cast(s16x8, f);
-        s = __builtin_elementwise_max(s, (s16x8)(0));
+        s = __builtin_elementwise_max(s, (s16x8)(lo));
         return __builtin_bit_cast(frag, s);
+    }
+    static __device__ __forceinline__ frag bias_frag(float b, bool lower_half) {
+        _Float16 hi = (_Float16)b;
+        _Float16 lo = (_Float16)(b - (float)hi);
+        frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (_Float16)0.0f;
+        if (lower_half) {
+            f[0] = hi;
+            f[1] = lo;
+        }
+        return f;
+    }
+    static __device__ __forceinline__ frag ones_frag() {
+        frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (_Float16)(j < 2 ? 1.0f : 0.0f);
+        return f;
     }
 };
 
-// The weight stream: chunk c lives in LDS buffer c&1 once advance() has returned for it.
-template <int WAVES>
+// The weight stream: X16_NCHUNK chunks of X16_CH pieces, staged L2 -> LDS by LDS-DMA into a ring of three
+// chunk buffers (chunk c lives in buffer c % 3), and read by every wave through a small register ring of
+// X16_DEPTH fragments so that the matrix pipe never waits for an LDS round trip:
+//   * the prologue stages chunks 0 and 1 and meets once;
+//   * rendezvous n (one workgroup barrier) is met X16_DEPTH pieces BEFORE the end of chunk n: it makes chunk
+//     n+1 visible (issued at rendezvous n-1) and issues chunk n+2 into the buffer of chunk n-1, which every
+//     wave has left by then -- so fragment prefetches run across chunk boundaries without a bubble;
+//   * X16_STAGGER: waves WAVES/2.. (the SIMD partners of waves 0..) meet half a chunk earlier in THEIR stream,
+//     i.e. they run half a chunk behind, so one wave's accumulator epilogue overlaps its partner's MFMAs.
+#ifndef X16_STAGGER
+#define X16_STAGGER 0
+#endif
+#ifndef X16_DEPTH
+#define X16_DEPTH 2
+#endif
+#define X16_NBUF 3
+#define X16_CHUNK_BYTES (X16_CH * X16_PIECE)
+
+// Diagnostic build only (-DX16_STAMP): per-wave cycle sums of the three phases of a tile, written to the
+// `wlocal` debug buffer (never read by the library).  Not for timing the kernel: the stamps fence overlap.
+#ifdef X16_STAMP
+__device__ __forceinline__ unsigned long long x16_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define X16_T(x) x
+#else
+#define X16_T(x)
+#endif
+
+template <int PREC, int WAVES>
 struct WeightStream {
+    X16_T(unsigned long long t_rv = 0; unsigned long long t_mfma = 0; unsigned long long t_epi = 0; unsigned long long t_bias = 0;
+          int tile_no = 0; float* tl = nullptr;)
+    typedef typename X16<PREC>::frag frag;
     const unsigned char* gsrc;  // per-lane: packed + (wave*PPW)*1KiB + lane*16
-    unsigned char* ring;        // LDS, 2 * X16_CH KiB
-    const unsigned char* cur;   // LDS buffer of the chunk being consumed (+ lane*16)
-    int chunk;                  // next chunk to hand out
-    int wave, lane;
+    unsigned char* ring;        // LDS, 3 chunk buffers
+    const unsigned char* base;  // ring + lane*16
+    int cur_off, nxt_off;       // byte offsets of the buffers of chunk `chunk` and `chunk`+1
+    int chunk;                  // chunk of the piece being consumed
+    int meets;                  // rendezvous done so far
+    int wave;
+    frag a[X16_DEPTH];          // piece p sits in a[p % X16_DEPTH]
     static constexpr int PPW = X16_CH / WAVES;  // pieces each wave stages per chunk
 
     __device__ __forceinline__ void issue(int c) {
-        const unsigned char* src = gsrc + (size_t)c * X16_CH * X16_PIECE;
-        unsigned char* dst = ring + (c & 1) * X16_CH * X16_PIECE + wave * PPW * X16_PIECE;
+        const unsigned char* src = gsrc + (size_t)c * X16_CHUNK_BYTES;
+        unsigned char* dst = ring + (c % X16_NBUF) * X16_CHUNK_BYTES + wave * PPW * X16_PIECE;
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + i * X16_PIECE), (LDS_AS void*)(dst + i * X16_PIECE), 16, 0,
                                              0);
     }
-    __device__ __forceinline__ void advance() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk `chunk` have landed
-        __syncthreads();                                   // everyone's have; everyone is done with the other buffer
-        if (chunk + 1 < X16_NCHUNK) issue(chunk + 1);
-        cur = ring + (chunk & 1) * X16_CH * X16_PIECE + lane * 16;
-        ++chunk;
+    __device__ __forceinline__ void prologue_issue() {
+        issue(0);
+        issue(1);
+    }
+    __device__ __forceinline__ void prologue_wait() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        chunk = 0;
+        meets = 0;
+        cur_off = 0;
+        nxt_off = X16_CHUNK_BYTES;
+#pragma unroll
+        for (int j = 0; j < X16_DEPTH - 1; ++j) a[j] = *reinterpret_cast<const frag*>(base + j * X16_PIECE);
+    }
+    __device__ __forceinline__ void rendezvous() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk meets+1 have landed
+        __syncthreads();                                   // everyone's have; everyone has left chunk meets-1
+        if (meets + 2 < X16_NCHUNK) issue(meets + 2);
+        ++meets;
+    }
+    // Fragment of stage-local piece p (compile-time after unrolling; stages are whole chunks, so p % X16_CH and
+    // p % X16_DEPTH equal their stream-global values).  LAST/NP: the final stage must not prefetch past the stream.
+    template <bool LATE, bool LAST, int NP>
+    __device__ __forceinline__ frag next(const int p) {
+        const int rv = (LATE ? X16_CH / 2 : X16_CH) - X16_DEPTH;
+        if (p % X16_CH == rv) {
+            X16_T(const unsigned long long r0 = x16_now();)
+            rendezvous();
+            X16_T(t_rv += x16_now() - r0;)
+        }
+        const int q = p + X16_DEPTH - 1;
+        if (!(LAST && q >= NP)) {
+            const int off = (q % X16_CH < p % X16_CH) ? nxt_off : cur_off;
+            a[q % X16_DEPTH] = *reinterpret_cast<const frag*>(base + off + (q % X16_CH) * X16_PIECE);
+        }
+        const frag r = a[p % X16_DEPTH];
+        if ((p + 1) % X16_CH == 0) {
+            ++chunk;
+            cur_off = nxt_off;
+            nxt_off = ((chunk + 1) % X16_NBUF) * X16_CHUNK_BYTES;
+        }
+        return r;
     }
 };
 
@@ -136,43 +248,38 @@ __device__ __forceinline__ float butterfly32(float (&v)[32], const int c) {
 // stage L0) or the wave's LDS copy (pe_lds, skip stage L5); the rest come from hin.
 // `bias` is wave-uniform, so the 32 values of a tile arrive by scalar loads; lane half h picks
 // rows (r&3)+8(r>>2)+4h of the tile.
-template <int PREC, int NB, int WAVES, int KS, int KPE, int NT, int MODE>
-__device__ __forceinline__ void x16_stage(WeightStream<WAVES>& ws, const float* __restrict__ bias,
+template <int PREC, int NB, int WAVES, bool LATE, int KS, int KPE, int NT, int MODE>
+__device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const float* __restrict__ bias,
                                           const typename X16<PREC>::frag (&pe_reg)[NB][4], const unsigned char* pe_lds,
                                           const typename X16<PREC>::frag (&hin)[NB][24], typename X16<PREC>::frag (&hout)[NB][24],
-                                          float (&aux)[NB], float* const (&po)[NB], const bool (&live)[NB], const int lane) {
+                                          float (&aux)[NB], float* const (&po)[NB], const bool (&live)[NB], const int lane,
+                                          const short relu_lo = 0) {
     typedef typename X16<PREC>::frag frag;
     const int h = lane >> 5, c = lane & 31;
     float red[NB][32];
-    frag a_cur;
+    const frag ones = X16<PREC>::ones_frag();
+    float bias_cur = bias[c];
 #pragma unroll
     for (int ot = 0; ot < NT; ++ot) {
         f32x16 acc[NB];
+        X16_T(const unsigned long long s0 = x16_now();)
         {
-            const float* bt = bias + ot * 32;
-            f32x16 binit;
+            // acc = bias, broadcast over the samples, by ONE extra MFMA (hi/lo split keeps ~16 mantissa bits):
+            // lane r of the lower half holds bias[ot*32 + r], fetched one tile ahead
+            const frag bf = X16<PREC>::bias_frag(bias_cur, h == 0);
+            if (ot + 1 < NT) bias_cur = bias[(ot + 1) * 32 + c];
+            f32x16 zero;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row0 = (r & 3) + 8 * (r >> 2);
-                const float b0 = bt[row0], b1 = bt[row0 + 4];
-                binit[r] = h ? b1 : b0;
-            }
+            for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
+            const f32x16 binit = X16<PREC>::mfma(bf, ones, zero);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[nb] = binit;
         }
+        X16_T(const unsigned long long s1 = x16_now(); const unsigned long long rv0 = ws.t_rv;)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int p = ot * KS + ks;  // compile-time after unrolling
-            if (p % X16_CH == 0) {
-                ws.advance();
-                a_cur = *reinterpret_cast<const frag*>(ws.cur + (p % X16_CH) * X16_PIECE);
-            }
-#if X16_PREFETCH
-            // fetch the next piece of this chunk (it may belong to the next out tile) before issuing
-            // this piece's MFMA, so one fragment read is always in flight behind the matrix pipe
-            frag a_nxt = a_cur;
-            if ((p + 1) % X16_CH != 0) a_nxt = *reinterpret_cast<const frag*>(ws.cur + ((p + 1) % X16_CH) * X16_PIECE);
-#endif
+            const frag a_cur = ws.template next<LATE, MODE == MODE_COMPOSITE, NT * KS>(p);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 frag b;
@@ -184,16 +291,8 @@ __device__ __forceinline__ void x16_stage(WeightStream<WAVES>& ws, const float* 
                 }
                 acc[nb] = X16<PREC>::mfma(a_cur, b, acc[nb]);
             }
-#if X16_PREFETCH
-            a_cur = a_nxt;
-#if X16_PREFETCH > 1
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NB, 0);
-#endif
-#else
-            if ((p + 1) % X16_CH != 0) a_cur = *reinterpret_cast<const frag*>(ws.cur + ((p + 1) % X16_CH) * X16_PIECE);
-#endif
         }
+        X16_T(const unsigned long long s2 = x16_now();)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             if (MODE == MODE_HIDDEN || MODE == MODE_LINEAR) {
@@ -202,8 +301,8 @@ __device__ __forceinline__ void x16_stage(WeightStream<WAVES>& ws, const float* 
                 for (int r = 0; r < 16; ++r) v[r] = acc[nb][r];
                 frag f0 = X16<PREC>::pack(v), f1 = X16<PREC>::pack(v + 8);
                 if (MODE == MODE_HIDDEN) {
-                    f0 = X16<PREC>::relu(f0);
-                    f1 = X16<PREC>::relu(f1);
+                    f0 = X16<PREC>::relu(f0, relu_lo);
+                    f1 = X16<PREC>::relu(f1, relu_lo);
                 }
                 hout[nb][2 * ot + 0] = f0;
                 hout[nb][2 * ot + 1] = f1;
@@ -222,30 +321,32 @@ __device__ __forceinline__ void x16_stage(WeightStream<WAVES>& ws, const float* 
                 }
             }
         }
+        X16_T(const unsigned long long s3 = x16_now(); ws.t_bias += s1 - s0; ws.t_mfma += (s2 - s1) - (ws.t_rv - rv0); ws.t_epi += s3 - s2;
+              if (ws.tl && ws.tile_no >= 20 && ws.tile_no < 34 && (threadIdx.x & 63) == 0) {
+                  ws.tl[4 + 2 * (ws.tile_no - 20)] = (float)(s1 & 0xFFFFFF);
+                  ws.tl[5 + 2 * (ws.tile_no - 20)] = (float)(s2 & 0xFFFFFF);
+              }
+              ++ws.tile_no;)
     }
 }
 
-template <int PREC, int NB, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 1) void nerf_fwd_x16_kernel(
-    N3dtGeom g, const unsigned char* __restrict__ packed, const float* __restrict__ fold, const float* __restrict__ xy,
+template <int PREC, int NB, int WAVES, bool LATE>
+__device__ __forceinline__ void nerf_fwd_x16_body(
+    const N3dtGeom& g, const unsigned char* __restrict__ packed, const float* __restrict__ fold, const float* __restrict__ xy,
     const float* __restrict__ R, const float* __restrict__ T, const float* __restrict__ Kinv, const float* __restrict__ t_rand,
-    float* __restrict__ part, float* __restrict__ wlocal, int bpr, long total_blocks) {
+    float* __restrict__ part, float* __restrict__ wlocal, int bpr, long total_blocks, unsigned char* lds, const int wave) {
     typedef typename X16<PREC>::frag frag;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
 
-    WeightStream<WAVES> ws;
-    ws.gsrc = packed + (size_t)wave * WeightStream<WAVES>::PPW * X16_PIECE + lane * 16;
+    WeightStream<PREC, WAVES> ws;
+    ws.gsrc = packed + (size_t)wave * WeightStream<PREC, WAVES>::PPW * X16_PIECE + lane * 16;
     ws.ring = lds;
-    ws.cur = lds;
-    ws.chunk = 0;
+    ws.base = lds + lane * 16;
     ws.wave = wave;
-    ws.lane = lane;
-    ws.issue(0);
+    ws.prologue_issue();  // the sampler / encoder below runs under these loads
     // per-wave LDS copy of the PE fragments for the skip stage: NB*4 lane-linear 1 KiB pieces
-    unsigned char* pe_lds = lds + 2 * X16_CH * X16_PIECE + (size_t)wave * NB * 4 * X16_PIECE + lane * 16;
+    unsigned char* pe_lds = lds + X16_NBUF * X16_CH * X16_PIECE + (size_t)wave * NB * 4 * X16_PIECE + lane * 16;
 
     // block bookkeeping: the wave handles NB consecutive 32-sample blocks (all of one frame, host-checked)
     bool live[NB];
@@ -286,21 +387,25 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerf_fwd_x16_kernel(
         }
     }
     const float* fb = fold + (size_t)__builtin_amdgcn_readfirstlane(frame) * N3DT_FOLD_STRIDE;
+    ws.prologue_wait();
+    X16_T(if (wlocal && live[0]) ws.tl = wlocal + (size_t)blk[0] * X16_BS;)
 
     frag ha[NB][24], hb[NB][24];
     float aux[NB];
-    // FeaExt_module_0..7 with the skip concat after layer 4 (reference: NetWorks/models.py:69-76)
-    x16_stage<PREC, NB, WAVES, 4, 4, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(0), pe, nullptr, ha, ha, aux, po, live, lane);
-    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(1), pe, nullptr, ha, hb, aux, po, live, lane);
-    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(2), pe, nullptr, hb, ha, aux, po, live, lane);
-    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(3), pe, nullptr, ha, hb, aux, po, live, lane);
-    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(4), pe, nullptr, hb, ha, aux, po, live, lane);
-    x16_stage<PREC, NB, WAVES, 28, 4, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(5), pe, pe_lds, ha, hb, aux, po, live, lane);
-    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(6), pe, nullptr, hb, ha, aux, po, live, lane);
-    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(7), pe, nullptr, ha, hb, aux, po, live, lane);
-    // density head (models.py:78,84); the bias rides in the accumulator
-    x16_stage<PREC, NB, WAVES, 24, 0, 1, MODE_DENSITY>(ws, fb + n3dt_bias_offset(8), pe, nullptr, hb, ha, aux, po, live, lane);
-
+    // FeaExt_module_0 (reference: NetWorks/models.py:69-71)
+    x16_stage<PREC, NB, WAVES, LATE, 4, 4, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(0), pe, nullptr, ha, ha, aux, po, live, lane);
+    // FeaExt_module_1..7 with the skip concat after layer 4 (models.py:72-76).  Fully unrolled on purpose: rolling the
+    // identical 384->384 layers into a loop (tried: one-layer body + register copy, two-layer ping-pong body) makes the
+    // register allocator spill 120-270 VGPRs across the back edge and runs 1.7x slower.
+    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(1), pe, nullptr, ha, hb, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(2), pe, nullptr, hb, ha, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(3), pe, nullptr, ha, hb, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(4), pe, nullptr, hb, ha, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, LATE, 28, 4, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(5), pe, pe_lds, ha, hb, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(6), pe, nullptr, hb, ha, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 12, MODE_HIDDEN>(ws, fb + n3dt_bias_offset(7), pe, nullptr, ha, hb, aux, po, live, lane);
+    // density head on h7 (models.py:78,84); the bias rides in the accumulator
+    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 1, MODE_DENSITY>(ws, fb + n3dt_bias_offset(8), pe, nullptr, hb, ha, aux, po, live, lane);
     // alpha, in-block transmittance and weights (reference: NetWorks/utils.py:273-289)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -323,13 +428,38 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerf_fwd_x16_kernel(
             po[nb][N3DT_G + 2] = tprod;
             po[nb][N3DT_G + 3] = 0.0f;
         }
+#ifndef X16_STAMP
         if (live[nb] && wlocal && h == 0) wlocal[(size_t)blk[nb] * X16_BS + c] = w;
+#endif
         aux[nb] = w;
     }
-    // feature head (models.py:79-82): RGB_layer_0 (linear), RGB_layer_1 (+appearance fold, relu),
-    // weighted by the sample weights and reduced over the block's samples
-    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_LINEAR>(ws, fb + n3dt_bias_offset(9), pe, nullptr, hb, ha, aux, po, live, lane);
-    x16_stage<PREC, NB, WAVES, 24, 0, 6, MODE_COMPOSITE>(ws, fb + n3dt_bias_offset(10), pe, nullptr, ha, hb, aux, po, live, lane);
+    // RGB_layer_0 (linear, models.py:79)
+    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 12, MODE_LINEAR>(ws, fb + n3dt_bias_offset(9), pe, nullptr, hb, ha, aux, po, live, lane);
+    // RGB_layer_1 (+appearance fold, relu; models.py:80-81), weighted by the sample weights and reduced over the samples
+    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 6, MODE_COMPOSITE>(ws, fb + n3dt_bias_offset(10), pe, nullptr, ha, hb, aux, po, live, lane);
+#ifdef X16_STAMP
+    if (wlocal && lane == 0 && live[0]) {
+        float* dbg = wlocal + (size_t)blk[0] * X16_BS;
+        dbg[0] = (float)ws.t_bias;
+        dbg[1] = (float)ws.t_mfma;
+        dbg[2] = (float)ws.t_epi;
+        dbg[3] = (float)ws.t_rv;
+    }
+#endif
+}
+
+template <int PREC, int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 1) void nerf_fwd_x16_kernel(
+    N3dtGeom g, const unsigned char* __restrict__ packed, const float* __restrict__ fold, const float* __restrict__ xy,
+    const float* __restrict__ R, const float* __restrict__ T, const float* __restrict__ Kinv, const float* __restrict__ t_rand,
+    float* __restrict__ part, float* __restrict__ wlocal, int bpr, long total_blocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the two halves of the workgroup run the same stream half a chunk apart (see WeightStream)
+    if (X16_STAGGER && wave >= WAVES / 2)
+        nerf_fwd_x16_body<PREC, NB, WAVES, true>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, bpr, total_blocks, lds, wave);
+    else
+        nerf_fwd_x16_body<PREC, NB, WAVES, false>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, bpr, total_blocks, lds, wave);
 }
 
 template <int PREC, int NB, int WAVES>
@@ -339,7 +469,7 @@ static void launch_x16(const N3dtGeom* g, const void* packed, const float* fold,
     const long total = (long)g->batch * g->n_rays * bpr;
     const long per_wg = (long)WAVES * NB;
     const int grid = (int)((total + per_wg - 1) / per_wg);
-    const size_t lds_bytes = 2 * X16_CH * X16_PIECE + (size_t)WAVES * NB * 4 * X16_PIECE;
+    const size_t lds_bytes = X16_NBUF * X16_CH * X16_PIECE + (size_t)WAVES * NB * 4 * X16_PIECE;
     auto kern = nerf_fwd_x16_kernel<PREC, NB, WAVES>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, *g, reinterpret_cast<const unsigned char*>(packed),
