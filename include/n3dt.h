@@ -154,7 +154,9 @@ int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, int precision, const N3dtR
  *   accumulates parameter gradients into `grads`, adds dL/d(bg_featmap) [C,N_r] into d_bg_featmap (nullable)
  *   and writes dL/d(shape) [B,shape_dim], dL/d(appea) [B,appea_dim], dL/d(audio) [B,audio_dim] (each nullable).
  *   Differentiates NetWorks/models.py:62-87, NetWorks/utils.py:268-309, NetWorks/HeadNeRFNet.py:84-112,149-152.
- *   (Gradients to the cameras, SURVEY 8f-1, are not built yet.) */
+ *   Camera gradients (the fitting use-case, FittingSingleImage_new.py:826-859): when d_R [B,3,3] and/or d_T [B,3]
+ *   are non-NULL they receive dL/d(batch_Rmats), dL/d(batch_Tvecs); xy, R, T, Kinv (and t_rand if the forward
+ *   used it) must then be the forward's inputs.  Pass NULL for all seven to skip that work. */
 size_t n3dt_render_train_saved_bytes(const N3dtGeom* g);
 size_t n3dt_render_train_workspace_bytes(const N3dtGeom* g);
 int n3dt_render_train_fwd(const N3dtGeom* g, const void* packed_mlp, const N3dtMlpParams* p,
@@ -167,6 +169,8 @@ int n3dt_render_bwd(const N3dtGeom* g, const N3dtMlpParams* p, const N3dtMlpGrad
                     const float* d_merge_feat, const float* d_fg_feat, const float* d_bg_alpha,
                     const void* saved, size_t saved_bytes,
                     float* d_bg_featmap, float* d_shape, float* d_appea, float* d_audio,
+                    const float* xy, const float* R, const float* T, const float* Kinv, const float* t_rand,
+                    float* d_R, float* d_T,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* Neural renderer with saved activations, and its backward (differentiates NetWorks/neural_renderer.py:72-91,

@@ -25,8 +25,8 @@ void n3dt_launch_train_fwd(const N3dtGeom*, const N3dtMlpParams*, const float*, 
                            const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, float*,
                            float*, hipStream_t);
 void n3dt_launch_train_bwd(const N3dtGeom*, const N3dtMlpParams*, const N3dtMlpGrads*, const float*, const float*, const float*,
-                           const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, float*,
-                           hipStream_t);
+                           const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*,
+                           const float*, const float*, const float*, const float*, const float*, float*, float*, float*, hipStream_t);
 size_t n3dt_nr_train_saved_floats(const N3dtGeom*, int);
 size_t n3dt_nr_train_ws_floats(const N3dtGeom*, int);
 void n3dt_launch_nr_train_fwd(const N3dtGeom*, int, const N3dtRenderParams*, const float*, float*, float*, float*, hipStream_t);
@@ -239,7 +239,8 @@ extern "C" int n3dt_render_train_fwd(const N3dtGeom* g, const void* packed_mlp, 
 extern "C" int n3dt_render_bwd(const N3dtGeom* g, const N3dtMlpParams* p, const N3dtMlpGrads* grads, const float* shape,
                                const float* appea, const float* audio, const float* bg_featmap, const float* d_merge_feat,
                                const float* d_fg_feat, const float* d_bg_alpha, const void* saved, size_t saved_bytes,
-                               float* d_bg_featmap, float* d_shape, float* d_appea, float* d_audio, void* workspace,
+                               float* d_bg_featmap, float* d_shape, float* d_appea, float* d_audio, const float* xy, const float* R,
+                               const float* T, const float* Kinv, const float* t_rand, float* d_R, float* d_T, void* workspace,
                                size_t workspace_bytes, void* stream) {
     int rc = check_train_geom(g);
     if (rc) return rc;
@@ -251,8 +252,10 @@ extern "C" int n3dt_render_bwd(const N3dtGeom* g, const N3dtMlpParams* p, const 
         if (!grads->weight[l] || !grads->bias[l]) return fail(N3DT_EINVAL, "n3dt_render_bwd: NULL gradient pointer");
     if (saved_bytes < n3dt_render_train_saved_bytes(g)) return fail(N3DT_EWORKSPACE, "n3dt_render_bwd: saved buffer too small");
     if (workspace_bytes < n3dt_render_train_workspace_bytes(g)) return fail(N3DT_EWORKSPACE, "n3dt_render_bwd: workspace too small");
+    if ((d_R || d_T) && (!xy || !R || !T || !Kinv)) return fail(N3DT_EINVAL, "n3dt_render_bwd: camera gradients need xy, R, T, Kinv");
     n3dt_launch_train_bwd(g, p, grads, shape, appea, audio, bg_featmap, d_merge_feat, d_fg_feat, d_bg_alpha, (const float*)saved,
-                          d_bg_featmap, d_shape, d_appea, d_audio, (float*)workspace, (hipStream_t)stream);
+                          d_bg_featmap, d_shape, d_appea, d_audio, xy, R, T, Kinv, t_rand, d_R, d_T, (float*)workspace,
+                          (hipStream_t)stream);
     return check_hip("n3dt_render_bwd");
 }
 

@@ -40,7 +40,7 @@ static TrainSaved saved_layout(const N3dtGeom* g) {
 }
 
 struct TrainWs {  // float offsets into the workspace
-    size_t w5p, wc, bc, dha, dhb, dxr, dg, dgray, dwsum, dw5p, dwc, dfold, total;
+    size_t w5p, wc, bc, dha, dhb, dxr, dg, dgray, dwsum, dw5p, dwc, dfold, dpe, total;
 };
 
 static TrainWs ws_layout(const N3dtGeom* g) {
@@ -59,6 +59,7 @@ static TrainWs ws_layout(const N3dtGeom* g) {
     w.dw5p = o; o += al64(384 * 448);
     w.dwc = o; o += al64(385 * 384);
     w.dfold = o; o += al64((size_t)g->batch * N3DT_FOLD_STRIDE);
+    w.dpe = o; o += al64(P * 64);  // d PE, only touched when camera gradients are requested
     w.total = o;
     return w;
 }
@@ -279,7 +280,10 @@ __global__ void train_composite_bwd_kernel(N3dtGeom g, const float* __restrict__
         }
         float dsig = dalpha * dist * e;
         if (!(sig > 0.0f)) dsig = 0.0f;
-        if (s < Ns) dxr[(p0 + s) * XR_LD + 384] = dsig;
+        if (s < Ns) {
+            dxr[(p0 + s) * XR_LD + 384] = dsig;
+            dxr[(p0 + s) * XR_LD + 385] = dalpha * sigma * e;  // d dist (pad column; consumed by the camera backward only)
+        }
         carry += __shfl(incl, 0, 64);
         // dG rows
         for (int k = 0; k < n; ++k) {
@@ -288,6 +292,94 @@ __global__ void train_composite_bwd_kernel(N3dtGeom g, const float* __restrict__
             float* dgo = dG + (p0 + s0 + k) * 192;
 #pragma unroll
             for (int i = 0; i < 3; ++i) dgo[lane + 64 * i] = gr[lane + 64 * i] > 0.0f ? wk * dgr[i] : 0.0f;
+        }
+    }
+}
+
+// Camera backward (the single-image fitting use-case): one wave per ray.
+//   p_s = T + (d l) z_s,  dist_s = (z_{s+1} - z_s) l,  d = w/|w|,  w = R c,  c = Kinv [x, y, 1],  l = -1/d_z
+//   PE rows: [p, sin(2^k p), cos(2^k p)]  ->  dp = dPE_p + sum_k 2^k (cos * dPE_sin - sin * dPE_cos)
+// every sample edge moves 1:1 with T_z (utils.py:125-126,142 and the convex jitter of :73-78), so dist does not
+// depend on T and the edge term of the points is dp . (d l).
+__global__ void train_camera_bwd_kernel(N3dtGeom g, const float* __restrict__ xy, const float* __restrict__ R,
+                                        const float* __restrict__ T, const float* __restrict__ Kinv,
+                                        const float* __restrict__ t_rand, const float* __restrict__ cat5,
+                                        const float* __restrict__ dpe, const float* __restrict__ dxr, float* __restrict__ d_R,
+                                        float* __restrict__ d_T) {
+    const long Rr = (long)g.batch * g.n_rays;
+    const long rayg = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (rayg >= Rr) return;
+    const int ray = (int)(rayg % g.n_rays), b = (int)(rayg / g.n_rays), Ns = g.n_samples;
+    const float* Rb = R + b * 9;
+    const float* Kb = Kinv + b * 9;
+    const float* Tb = T + b * 3;
+    const float x = xy[(int64_t)b * g.xy_stride_b + (int64_t)ray * g.xy_stride_r];
+    const float y = xy[(int64_t)b * g.xy_stride_b + g.xy_stride_c + (int64_t)ray * g.xy_stride_r];
+    float c[3], w[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c[i] = Kb[i * 3 + 0] * x + Kb[i * 3 + 1] * y + Kb[i * 3 + 2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w[i] = Rb[i * 3 + 0] * c[0] + Rb[i * 3 + 1] * c[1] + Rb[i * 3 + 2] * c[2];
+    const float n = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const float dh[3] = {w[0] / n, w[1] / n, w[2] / n};
+    const float l = -1.0f / dh[2];
+    const float dl[3] = {dh[0] * l, dh[1] * l, dh[2] * l};
+    const float rz1 = Tb[2] - g.world_z1, rz2 = Tb[2] - g.world_z2;
+    const float* tr = t_rand ? t_rand + ((int64_t)b * g.n_rays + ray) * (Ns + 1) : nullptr;
+    float g_dl[3] = {0.f, 0.f, 0.f}, g_T[3] = {0.f, 0.f, 0.f}, g_l = 0.0f, g_tz = 0.0f;
+    for (int s = lane; s < Ns; s += 64) {
+        const size_t pt = (size_t)rayg * Ns + s;
+        const float* pe = cat5 + pt * 448;
+        const float* dq = dpe + pt * 64;
+        float dp[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float acc = dq[d];
+            float f = 1.0f;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                const float sn = pe[3 + 6 * k + d], cs = pe[3 + 6 * k + 3 + d];
+                acc += f * (cs * dq[3 + 6 * k + d] - sn * dq[3 + 6 * k + 3 + d]);
+                f *= 2.0f;
+            }
+            dp[d] = acc;
+        }
+        const float z_lo = n3dt_edge_z(rz1, rz2, s, Ns, tr), z_hi = n3dt_edge_z(rz1, rz2, s + 1, Ns, tr);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            g_dl[d] += dp[d] * z_lo;
+            g_T[d] += dp[d];
+        }
+        g_tz += dp[0] * dl[0] + dp[1] * dl[1] + dp[2] * dl[2];
+        g_l += dxr[pt * XR_LD + 385] * (z_hi - z_lo);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            g_dl[d] += __shfl_xor(g_dl[d], off, 64);
+            g_T[d] += __shfl_xor(g_T[d], off, 64);
+        }
+        g_l += __shfl_xor(g_l, off, 64);
+        g_tz += __shfl_xor(g_tz, off, 64);
+    }
+    if (lane == 0) {
+        const float gl = g_l + g_dl[0] * dh[0] + g_dl[1] * dh[1] + g_dl[2] * dh[2];
+        float g_dh[3] = {g_dl[0] * l, g_dl[1] * l, g_dl[2] * l + gl * l * l};
+        const float dot = g_dh[0] * dh[0] + g_dh[1] * dh[1] + g_dh[2] * dh[2];
+        float g_w[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) g_w[d] = (g_dh[d] - dh[d] * dot) / n;
+        if (d_R)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) atomicAdd(&d_R[b * 9 + i * 3 + j], g_w[i] * c[j]);
+        if (d_T) {
+            atomicAdd(&d_T[b * 3 + 0], g_T[0]);
+            atomicAdd(&d_T[b * 3 + 1], g_T[1]);
+            atomicAdd(&d_T[b * 3 + 2], g_T[2] + g_tz);
         }
     }
 }
@@ -442,7 +534,8 @@ extern "C" void n3dt_launch_train_fwd(const N3dtGeom* g, const N3dtMlpParams* p,
 extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p, const N3dtMlpGrads* gp, const float* shape,
                                       const float* appea, const float* audio, const float* bg_featmap, const float* d_merge,
                                       const float* d_fg, const float* d_ba, const float* saved, float* d_bg_featmap, float* d_shape,
-                                      float* d_appea, float* d_audio, float* ws, hipStream_t s) {
+                                      float* d_appea, float* d_audio, const float* xy, const float* Rm, const float* Tv,
+                                      const float* Kinv, const float* t_rand, float* d_R, float* d_T, float* ws, hipStream_t s) {
     const TrainSaved sv = saved_layout(g);
     const TrainWs wl = ws_layout(g);
     const int P = g->batch * g->n_rays * g->n_samples, ppf = g->n_rays * g->n_samples;
@@ -520,6 +613,20 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
                                (long)N3DT_FOLD_STRIDE);
         } else {
             hipLaunchKernelGGL(train_colsum_kernel, dim3(2, 128, 1), dim3(256), 0, s, dcur, 384L, P, 384, gp->bias[l], 0L);
+        }
+        const bool want_cam = d_R || d_T;
+        if (want_cam && l == 5) {  // d PE from the skip layer: dH5 W5'[:, 0:64]
+            Gemm32 q = mk(P, 64, 384, dcur, 384, 0, ws + wl.w5p, 448, 1, ws + wl.dpe, 64);
+            n3dt_gemm32(q, s);
+        }
+        if (want_cam && l == 0) {  // += dH0 W0[:, 0:63]
+            Gemm32 q = mk(P, 63, 384, dcur, 384, 0, p->weight[0], 63 + S + U, 1, ws + wl.dpe, 64);
+            q.accumulate = 1;
+            n3dt_gemm32(q, s);
+            if (d_R) (void)hipMemsetAsync(d_R, 0, sizeof(float) * 9 * B, s);
+            if (d_T) (void)hipMemsetAsync(d_T, 0, sizeof(float) * 3 * B, s);
+            hipLaunchKernelGGL(train_camera_bwd_kernel, dim3((unsigned)((Rr + 3) / 4)), dim3(256), 0, s, *g, xy, Rm, Tv, Kinv, t_rand, cat5,
+                               ws + wl.dpe, dxr, d_R, d_T);
         }
         if (l == 0) break;
         // input gradient: dH_{l-1} = (dH_l W_l) * relu'(H_{l-1})

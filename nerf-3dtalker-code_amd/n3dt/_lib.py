@@ -90,7 +90,7 @@ def lib():
     L.n3dt_render_train_fwd.restype = ci
     L.n3dt_render_train_fwd.argtypes = [gp, vp, mp] + [vp] * 13 + [vp, sz, vp, sz, vp]
     L.n3dt_render_bwd.restype = ci
-    L.n3dt_render_bwd.argtypes = [gp, mp, mp] + [vp] * 7 + [vp, sz] + [vp] * 4 + [vp, sz, vp]
+    L.n3dt_render_bwd.argtypes = [gp, mp, mp] + [vp] * 7 + [vp, sz] + [vp] * 11 + [vp, sz, vp]
     L.n3dt_neural_render_train_saved_bytes.restype = sz
     L.n3dt_neural_render_train_saved_bytes.argtypes = [gp, ci]
     L.n3dt_neural_render_train_workspace_bytes.restype = sz

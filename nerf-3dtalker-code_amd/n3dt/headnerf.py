@@ -165,11 +165,15 @@ class NeuralRenderer(nn.Module):
 
 class _RenderFn(torch.autograd.Function):
     """a1..a7 with saved activations (n3dt_render_train_fwd) and its backward (n3dt_render_bwd).
-    Inputs after `net`/`geom`: xy, R, T, Kinv, t_rand (no grad), then shape, appea, audio, bg_featmap and the
-    24 MLP parameter tensors (all differentiable).  Camera gradients are not built yet."""
+    Inputs after `net`/`geom`: xy, Kinv, t_rand (no grad), then R, T, shape, appea, audio, bg_featmap and the
+    24 MLP parameter tensors (all differentiable; R/T gradients are computed only when they require grad)."""
 
     @staticmethod
-    def forward(ctx, net, geom, xy, R, T, Kinv, t_rand, shape, appea, audio, bg_featmap, *mlp):
+    def forward(ctx, net, geom, xy, Kinv, t_rand, R, T, shape, appea, audio, bg_featmap, *mlp):
+        ctx.want_cam = R.requires_grad or T.requires_grad
+        ctx.T_shape = T.shape
+        R = ops._f32c(R)
+        T = ops._f32c(T).view(-1, 3)
         ws = [t.detach().view(t.shape[0], -1).contiguous() for t in mlp[:12]]
         bs = [t.detach().contiguous() for t in mlp[12:]]
         params = ops.mlp_params(ws, bs)
@@ -179,6 +183,7 @@ class _RenderFn(torch.autograd.Function):
         bg = bg_featmap.detach().reshape(geom.feat_nc, -1).contiguous()
         out, saved = ops.render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape_c, appea_c, audio_c, t_rand, bg)
         ctx.geom, ctx.saved, ctx.keep = geom, saved, (ws, bs, shape_c, appea_c, audio_c, bg)
+        ctx.cam = (xy, R, T, Kinv, t_rand) if ctx.want_cam else None
         ctx.bg_shape = bg_featmap.shape
         ctx.mlp_shapes = [t.shape for t in mlp]
         return out["merge_feat"]
@@ -189,11 +194,13 @@ class _RenderFn(torch.autograd.Function):
         geom = ctx.geom
         gws = [torch.zeros_like(w) for w in ws]
         gbs = [torch.zeros_like(b) for b in bs]
-        d_bg, d_shape, d_appea, d_audio = ops.render_bwd(geom, ops.mlp_params(ws, bs), ops.mlp_params(gws, gbs), shape_c, appea_c,
-                                                         audio_c, bg, d_merge.contiguous(), ctx.saved)
+        d_bg, d_shape, d_appea, d_audio, d_R, d_T = ops.render_bwd(geom, ops.mlp_params(ws, bs), ops.mlp_params(gws, gbs), shape_c,
+                                                                   appea_c, audio_c, bg, d_merge.contiguous(), ctx.saved, ctx.cam)
         ctx.saved = None
         grads = [g.view(s) for g, s in zip(gws + gbs, ctx.mlp_shapes)]
-        return (None, None, None, None, None, None, None, d_shape, d_appea, d_audio, d_bg.view(ctx.bg_shape), *grads)
+        if d_T is not None:
+            d_T = d_T.view(ctx.T_shape)
+        return (None, None, None, None, None, d_R, d_T, d_shape, d_appea, d_audio, d_bg.view(ctx.bg_shape), *grads)
 
 
 class _NeuralRenderFn(torch.autograd.Function):
@@ -346,10 +353,8 @@ class HeadNeRFNet(nn.Module):
         return {"coarse_dict": {"merge_img": imgs[:batch_size], "bg_img": imgs[batch_size:]}}
 
     def _forward_train(self, batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand):
-        """Differentiable forward (exact fp32): gradients reach every parameter, audiostyle, shape_code, appea_code."""
-        for t, name in ((batch_Rmats, "batch_Rmats"), (batch_Tvecs, "batch_Tvecs")):
-            if torch.is_tensor(t) and t.requires_grad:
-                raise NotImplementedError("gradients w.r.t. %s (camera fitting, SURVEY 8f-1) are not built yet" % name)
+        """Differentiable forward (exact fp32): gradients reach every parameter, audiostyle, shape_code, appea_code and
+        (when they require grad) batch_Rmats / batch_Tvecs."""
         B, _, n_r = batch_xy.size()
         fs, C = self.featmap_size, self.featmap_nc
         xy = batch_xy if batch_xy.dtype == torch.float32 else batch_xy.float()
@@ -357,9 +362,8 @@ class HeadNeRFNet(nn.Module):
         layers = self.fg_CD_predictor.layers()
         mlp = [m.weight for m in layers] + [m.bias for m in layers]
         audio = audiostyle if self.audio_dim > 0 else torch.zeros(B, 0, device=xy.device)
-        merge = _RenderFn.apply(self, geom, xy.detach(), ops._f32c(batch_Rmats), ops._f32c(batch_Tvecs).view(B, 3),
-                                ops._f32c(batch_inv_inmats), None if t_rand is None else ops._f32c(t_rand),
-                                shape_code, appea_code, audio, self.neural_render.bg_featmap, *mlp)
+        merge = _RenderFn.apply(self, geom, xy.detach(), ops._f32c(batch_inv_inmats), None if t_rand is None else ops._f32c(t_rand),
+                                batch_Rmats, batch_Tvecs, shape_code, appea_code, audio, self.neural_render.bg_featmap, *mlp)
         bg_hwc = self.neural_render.bg_featmap.view(C, fs * fs).t().reshape(1, fs, fs, C)
         maps = torch.cat([merge.view(B, fs, fs, C), bg_hwc], dim=0)
         imgs = self.neural_render.render_hwc_train(maps)

@@ -166,22 +166,29 @@ def render_train_fwd(geom, packed_f32, params, xy, R, T, Kinv, shape, appea, aud
     return out, saved
 
 
-def render_bwd(geom, params, grads, shape, appea, audio, bg_featmap, d_merge, saved):
+def render_bwd(geom, params, grads, shape, appea, audio, bg_featmap, d_merge, saved, cam=None):
     """Backward of render_train_fwd.  `grads` (MlpParams struct of zeroed tensors) is accumulated into.
-    Returns (d_bg_featmap [C,Nr], d_shape, d_appea, d_audio)."""
+    cam = (xy, R, T, Kinv, t_rand) requests camera gradients.
+    Returns (d_bg_featmap [C,Nr], d_shape, d_appea, d_audio, d_R, d_T)."""
     dev = d_merge.device
     B, Nr, C = geom.batch, geom.n_rays, geom.feat_nc
     d_bg = torch.zeros(C, Nr, dtype=torch.float32, device=dev)
     d_shape = torch.empty(B, geom.shape_dim, dtype=torch.float32, device=dev)
     d_appea = torch.empty(B, geom.appea_dim, dtype=torch.float32, device=dev)
     d_audio = torch.empty(B, geom.audio_dim, dtype=torch.float32, device=dev) if geom.audio_dim > 0 else None
+    d_R = d_T = None
+    cam_ptrs = [None] * 5
+    if cam is not None:
+        d_R = torch.empty(B, 3, 3, dtype=torch.float32, device=dev)
+        d_T = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        cam_ptrs = [_ptr(t) for t in cam]
     wbytes = lib().n3dt_render_train_workspace_bytes(ctypes.byref(geom))
     ws = WORKSPACE.get("train", wbytes, dev)
     check(lib().n3dt_render_bwd(
         ctypes.byref(geom), ctypes.byref(params), ctypes.byref(grads), _ptr(shape), _ptr(appea), _ptr(audio), _ptr(bg_featmap),
         _ptr(d_merge), None, None, _ptr(saved), saved.numel(), _ptr(d_bg), _ptr(d_shape), _ptr(d_appea), _ptr(d_audio),
-        _ptr(ws), wbytes, _stream()), "n3dt_render_bwd")
-    return d_bg, d_shape, d_appea, d_audio
+        *cam_ptrs, _ptr(d_R), _ptr(d_T), _ptr(ws), wbytes, _stream()), "n3dt_render_bwd")
+    return d_bg, d_shape, d_appea, d_audio, d_R, d_T
 
 
 def neural_render_train_fwd(geom, nb, rparams, featmap):

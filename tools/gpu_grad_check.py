@@ -22,7 +22,7 @@ def run(name):
     net = HeadNeRFNet(opt, False, False).to(dev)
     net.load_state_dict(sd, strict=True)
     d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
-    for k in ("audiostyle", "shape_code", "appea_code"):
+    for k in ("audiostyle", "shape_code", "appea_code", "batch_Rmats", "batch_Tvecs"):
         d[k] = d[k].clone().requires_grad_(True)
     t_rand = None
     if m["mode"] == "train":
@@ -37,7 +37,7 @@ def run(name):
     total = terms["bg_loss"] + terms["head_loss"] + terms["nonhead_loss"]
     print("  loss terms", [float(terms[k]) for k in ("bg_loss", "head_loss", "nonhead_loss")], "golden", g["loss_terms"])
     total.backward()
-    for k in ("audiostyle", "shape_code", "appea_code"):
+    for k in ("audiostyle", "shape_code", "appea_code", "batch_Rmats", "batch_Tvecs"):
         ref = g["grad_in." + k]
         got = d[k].grad.cpu().numpy()
         print("  d%-11s max|err| %.2e  (max|ref| %.2e)" % (k, np.abs(got - ref).max(), np.abs(ref).max()))
