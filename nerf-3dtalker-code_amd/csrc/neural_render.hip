@@ -74,123 +74,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// 16-bit MFMA variant of the pixel GEMM (bf16 or f16 inputs converted while staging, fp32
-// accumulate): 128x128 tile, 4 waves x (2x2) 32x32 accumulators, BK = 32.
-// EPI_PSU additionally walks the output columns in pixel-shuffled order n' = (2di+dj)*C + c
-// (weight row o = 4c + 2di + dj), so a half-wave stores 128 contiguous bytes of one output pixel.
-// ---------------------------------------------------------------------------------------------
-typedef __bf16 nr_bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-
-template <int PREC>
-__device__ __forceinline__ unsigned short to_x16(float v) {
-    if (PREC == N3DT_BF16) return __builtin_bit_cast(unsigned short, (__bf16)v);
-    return __builtin_bit_cast(unsigned short, (_Float16)v);
-}
-
-#define XG_BM 128
-#define XG_BN 128
-#define XG_BK 32
-#define XG_LD (XG_BK + 8)  // halves per LDS row: 80 B rows keep the 16-byte fragment reads spread over the banks
-
-template <int EPI, int PREC>
-__global__ __launch_bounds__(256) void gemm_x16_kernel(int M, int N, int K, const float* __restrict__ X,
-                                                       const float* __restrict__ Wt, const float* __restrict__ bias,
-                                                       GemmEpi ea) {
-    __shared__ __attribute__((aligned(16))) unsigned short As[XG_BM * XG_LD];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[XG_BN * XG_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * XG_BM, n0 = blockIdx.y * XG_BN;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    // staging: 128 rows x 32 k = 1024 float4 per operand, 4 per thread
-    for (int k0 = 0; k0 < K; k0 += XG_BK) {
-        f32x4 av[4], bv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 3, kq = idx & 7;
-            av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (m0 + row < M) av[i] = *reinterpret_cast<const f32x4*>(X + (size_t)(m0 + row) * K + k0 + 4 * kq);
-            int n = n0 + row;
-            if (n < N) {
-                if (EPI == EPI_PSU) n = 4 * (n % ea.C) + n / ea.C;  // pixel-shuffled column order
-                bv[i] = *reinterpret_cast<const f32x4*>(Wt + (size_t)n * K + k0 + 4 * kq);
-            }
-        }
-        __syncthreads();  // previous tile fully consumed
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 3, kq = idx & 7;
-            unsigned short* pa = As + row * XG_LD + 4 * kq;
-            unsigned short* pb = Bs + row * XG_LD + 4 * kq;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pa[j] = to_x16<PREC>(av[i][j]);
-                pb[j] = to_x16<PREC>(bv[i][j]);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < XG_BK / 16; ++ks) {
-            u16x8 af[2], bf[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                af[t] = *reinterpret_cast<const u16x8*>(As + (wr * 64 + t * 32 + (lane & 31)) * XG_LD + 16 * ks + 8 * (lane >> 5));
-                bf[t] = *reinterpret_cast<const u16x8*>(Bs + (wc * 64 + t * 32 + (lane & 31)) * XG_LD + 16 * ks + 8 * (lane >> 5));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (PREC == N3DT_BF16)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nr_bf16x8, af[i]),
-                                                                            __builtin_bit_cast(nr_bf16x8, bf[j]), acc[i][j], 0, 0, 0);
-                    else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]),
-                                                                           __builtin_bit_cast(f16x8, bf[j]), acc[i][j], 0, 0, 0);
-                }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wc * 64 + j * 32 + (lane & 31);
-        if (n >= N) continue;
-        int o = n, c = 0, di = 0, dj = 0;
-        if (EPI == EPI_PSU) {
-            c = n % ea.C;
-            const int q = n / ea.C;
-            di = q >> 1;
-            dj = q & 1;
-            o = 4 * c + q;
-        }
-        const float bn = bias[o];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int m = m0 + wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                if (m >= M) continue;
-                float v = acc[i][j][reg] + bn;
-                if (ea.slope >= 0.0f) v = v > 0.0f ? v : v * ea.slope;
-                if (EPI == EPI_LRELU) {
-                    ea.y[(size_t)m * N + n] = v;
-                } else {
-                    v += ea.res[(size_t)m * ea.C + (o % ea.C)];
-                    const int w = m % ea.W, hh = (m / ea.W) % ea.H, img = m / (ea.W * ea.H);
-                    ea.y[(((size_t)img * 2 * ea.H + 2 * hh + di) * 2 * ea.W + 2 * w + dj) * ea.C + c] = v;
-                }
-            }
-    }
-}
-
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 // Blur on [nb,H,W,C]: one thread = one pixel x 4 channels
@@ -282,27 +165,17 @@ __global__ void rgb_up_kernel(int n_planes, int h, int w, const float* __restric
     y[i] = acc;
 }
 
+#include "neural_render_x16.inc"
+
 static inline int nr_ch(int C, int i) {
     int v = C >> i;
     return v < 32 ? 32 : v;
 }
 
-static void launch_gemm(int precision, int epi, int M, int N, int K, const float* X, const float* Wt, const float* b, GemmEpi ea,
-                        hipStream_t s) {
-    if (precision == N3DT_F32) {
-        dim3 grid((M + 63) / 64, (N + 63) / 64);
-        if (epi == EPI_LRELU) hipLaunchKernelGGL(gemm_f32_kernel<EPI_LRELU>, grid, dim3(256), 0, s, M, N, K, X, Wt, b, ea);
-        else hipLaunchKernelGGL(gemm_f32_kernel<EPI_PSU>, grid, dim3(256), 0, s, M, N, K, X, Wt, b, ea);
-        return;
-    }
-    dim3 grid((M + XG_BM - 1) / XG_BM, (N + XG_BN - 1) / XG_BN);
-    if (precision == N3DT_BF16) {
-        if (epi == EPI_LRELU) hipLaunchKernelGGL((gemm_x16_kernel<EPI_LRELU, N3DT_BF16>), grid, dim3(256), 0, s, M, N, K, X, Wt, b, ea);
-        else hipLaunchKernelGGL((gemm_x16_kernel<EPI_PSU, N3DT_BF16>), grid, dim3(256), 0, s, M, N, K, X, Wt, b, ea);
-    } else {
-        if (epi == EPI_LRELU) hipLaunchKernelGGL((gemm_x16_kernel<EPI_LRELU, N3DT_F16>), grid, dim3(256), 0, s, M, N, K, X, Wt, b, ea);
-        else hipLaunchKernelGGL((gemm_x16_kernel<EPI_PSU, N3DT_F16>), grid, dim3(256), 0, s, M, N, K, X, Wt, b, ea);
-    }
+static void launch_gemm(int epi, int M, int N, int K, const float* X, const float* Wt, const float* b, GemmEpi ea, hipStream_t s) {
+    dim3 grid((M + 63) / 64, (N + 63) / 64);
+    if (epi == EPI_LRELU) hipLaunchKernelGGL(gemm_f32_kernel<EPI_LRELU>, grid, dim3(256), 0, s, M, N, K, X, Wt, b, ea);
+    else hipLaunchKernelGGL(gemm_f32_kernel<EPI_PSU>, grid, dim3(256), 0, s, M, N, K, X, Wt, b, ea);
 }
 
 // workspace carve (floats): t1 | ps | bl | netA | netB | rgbA | rgbB
@@ -332,6 +205,10 @@ extern "C" size_t n3dt_nr_workspace_floats(const N3dtGeom* g, int nb) { return n
 extern "C" void n3dt_launch_neural_render(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p,
                                           const float* featmap, float* img, float* ws, hipStream_t s) {
     const NrCarve cv = nr_carve(g, nb);
+    if (precision != N3DT_F32) {  // 16-bit activations, blur commuted behind feat_layers (neural_render_x16.inc)
+        n3dt_launch_neural_render_x16(g, nb, precision, p, featmap, img, ws, cv.total, s);
+        return;
+    }
     float* t1 = ws;
     float* ps = t1 + cv.t1;
     float* bl = ps + cv.ps;
@@ -356,16 +233,16 @@ extern "C" void n3dt_launch_neural_render(const N3dtGeom* g, int nb, int precisi
         const int ci = nr_ch(C, i), co = nr_ch(C, i + 1);
         const int M = nb * h * h;
         GemmEpi e1 = {t1, nullptr, 0, 0, 0, 0.2f};
-        launch_gemm(precision, EPI_LRELU, M, 2 * ci, ci, net, p->psu1_w[i], p->psu1_b[i], e1, s);
+        launch_gemm(EPI_LRELU, M, 2 * ci, ci, net, p->psu1_w[i], p->psu1_b[i], e1, s);
         GemmEpi e2 = {ps, net, ci, h, h, 0.2f};
-        launch_gemm(precision, EPI_PSU, M, 4 * ci, 2 * ci, t1, p->psu2_w[i], p->psu2_b[i], e2, s);
+        launch_gemm(EPI_PSU, M, 4 * ci, 2 * ci, t1, p->psu2_w[i], p->psu2_b[i], e2, s);
         h *= 2;
         {
             size_t n = (size_t)nb * h * h * (ci / 4);
             hipLaunchKernelGGL(blur_nhwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nb, h, h, ci, ps, bl);
         }
         GemmEpi e3 = {cur, nullptr, 0, 0, 0, 0.2f};
-        launch_gemm(precision, EPI_LRELU, nb * h * h, co, ci, bl, p->feat_w[i], p->feat_b[i], e3, s);
+        launch_gemm(EPI_LRELU, nb * h * h, co, ci, bl, p->feat_w[i], p->feat_b[i], e3, s);
         const bool last = (i == nblk - 1);
         size_t npix = (size_t)nb * h * h;
         // rgb = rgb + feat_2_rgb_list[i+1](net); sigmoid after the last block (neural_renderer.py:82-88)
