@@ -17,6 +17,8 @@
 // Epilogue per 32-sample block: density -> alpha -> in-block transmittance scan over the 32
 // lanes -> weights; the RGB_layer_1 activations are weighted and reduced over the samples with a
 // 5-step butterfly, so the only HBM traffic per block is one 196-float partial.
+#include <type_traits>
+
 #include "n3dt_device.h"
 #include "n3dt_layout.h"
 
@@ -151,8 +153,8 @@ struct WeightStream {
     typedef typename X16<PREC>::frag frag;
     const unsigned char* gsrc;  // per-lane: packed + (wave*PPW)*1KiB + lane*16
     unsigned char* ring;        // LDS, 3 chunk buffers
-    const unsigned char* base;  // ring + lane*16
-    int cur_off, nxt_off;       // byte offsets of the buffers of chunk `chunk` and `chunk`+1
+    unsigned lds_addr0;         // LDS byte address of ring + lane*16
+    unsigned cur_addr, nxt_addr;  // LDS byte addresses (+ lane*16) of the buffers of chunk `chunk` and `chunk`+1
     int chunk;                  // chunk of the piece being consumed
     int meets;                  // rendezvous done so far
     int wave;
@@ -176,10 +178,16 @@ struct WeightStream {
         __syncthreads();
         chunk = 0;
         meets = 0;
-        cur_off = 0;
-        nxt_off = X16_CHUNK_BYTES;
-#pragma unroll
-        for (int j = 0; j < X16_DEPTH - 1; ++j) a[j] = *reinterpret_cast<const frag*>(base + j * X16_PIECE);
+        cur_addr = lds_addr0;
+        nxt_addr = lds_addr0 + X16_CHUNK_BYTES;
+        preload<0>();
+    }
+    template <int J>
+    __device__ __forceinline__ void preload() {
+        if constexpr (J < X16_DEPTH - 1) {
+            read_frag<J * X16_PIECE>(a[J], cur_addr);
+            preload<J + 1>();
+        }
     }
     __device__ __forceinline__ void rendezvous() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk meets+1 have landed
@@ -187,26 +195,40 @@ struct WeightStream {
         if (meets + 2 < X16_NCHUNK) issue(meets + 2);
         ++meets;
     }
-    // Fragment of stage-local piece p (compile-time after unrolling; stages are whole chunks, so p % X16_CH and
-    // p % X16_DEPTH equal their stream-global values).  LAST/NP: the final stage must not prefetch past the stream.
-    template <bool LATE, bool LAST, int NP>
-    __device__ __forceinline__ frag next(const int p) {
-        const int rv = (LATE ? X16_CH / 2 : X16_CH) - X16_DEPTH;
-        if (p % X16_CH == rv) {
+    // The fragment reads are issued from inline asm so that their completion can be awaited with a COUNTED
+    // s_waitcnt lgkmcnt(DEPTH-1): hipcc's own bookkeeping waits lgkmcnt(0) here, i.e. for the prefetch it has just
+    // issued, which puts a full LDS round trip in front of every other MFMA (45 % of the wave time parked).
+    // LDS returns in order, so "at most DEPTH-1 younger operations outstanding" means this piece has landed; younger
+    // compiler-issued LDS operations only make the wait more conservative.  The wait names the fragment as "+v", so
+    // the consuming MFMA cannot be scheduled above it.
+    template <int OFF>
+    __device__ __forceinline__ void read_frag(frag& dst, const unsigned addr) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
+    }
+    __device__ __forceinline__ void await_frag(frag& f) {
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "i"(X16_DEPTH - 1));
+    }
+    // Fragment of stage-local piece P (stages are whole chunks, so P % X16_CH and P % X16_DEPTH equal their
+    // stream-global values).  LAST/NP: the final stage must not prefetch past the end of the stream.
+    template <bool LATE, bool LAST, int NP, int P>
+    __device__ __forceinline__ frag next() {
+        constexpr int rv = (LATE ? X16_CH / 2 : X16_CH) - X16_DEPTH;
+        if (P % X16_CH == rv) {
             X16_T(const unsigned long long r0 = x16_now();)
             rendezvous();
             X16_T(t_rv += x16_now() - r0;)
         }
-        const int q = p + X16_DEPTH - 1;
-        if (!(LAST && q >= NP)) {
-            const int off = (q % X16_CH < p % X16_CH) ? nxt_off : cur_off;
-            a[q % X16_DEPTH] = *reinterpret_cast<const frag*>(base + off + (q % X16_CH) * X16_PIECE);
+        constexpr int Q = P + X16_DEPTH - 1;
+        if (!(LAST && Q >= NP)) {
+            const unsigned addr = (Q % X16_CH < P % X16_CH) ? nxt_addr : cur_addr;
+            read_frag<(Q % X16_CH) * X16_PIECE>(a[Q % X16_DEPTH], addr);
         }
-        const frag r = a[p % X16_DEPTH];
-        if ((p + 1) % X16_CH == 0) {
+        await_frag(a[P % X16_DEPTH]);
+        const frag r = a[P % X16_DEPTH];
+        if ((P + 1) % X16_CH == 0) {
             ++chunk;
-            cur_off = nxt_off;
-            nxt_off = ((chunk + 1) % X16_NBUF) * X16_CHUNK_BYTES;
+            cur_addr = nxt_addr;
+            nxt_addr = lds_addr0 + ((chunk + 1) % X16_NBUF) * X16_CHUNK_BYTES;
         }
         return r;
     }
@@ -225,6 +247,16 @@ __device__ __forceinline__ float pe_fast(const float p[3], const float rh[3], co
 }
 
 enum { MODE_HIDDEN = 0, MODE_LINEAR = 1, MODE_DENSITY = 2, MODE_COMPOSITE = 3 };
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N) -- the piece index has to reach the
+// inline-asm immediates as a constant expression
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 // sum over the 32 lanes of a half-wave of 32 per-lane values: lane c ends with value index rev5(c)
 __device__ __forceinline__ float butterfly32(float (&v)[32], const int c) {
@@ -259,9 +291,25 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
     float red[NB][32];
     const frag ones = X16<PREC>::ones_frag();
     float bias_cur = bias[c];
+    // Two accumulator sets: tile ot accumulates into acc[ot & 1] while the epilogue of tile ot-1 (pack to 16 bit,
+    // ReLU) is placed between this tile's MFMAs -- VALU work issues under the matrix pipe instead of after it.
+    f32x16 acc[2][NB];
+    auto finish_half = [&](const int t, const int half) {  // registers 8*half .. 8*half+7 of tile t -> k-step 2t+half
 #pragma unroll
-    for (int ot = 0; ot < NT; ++ot) {
-        f32x16 acc[NB];
+        for (int nb = 0; nb < NB; ++nb) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = acc[t & 1][nb][8 * half + r];
+            frag f = X16<PREC>::pack(v);
+            if (MODE == MODE_HIDDEN) f = X16<PREC>::relu(f, relu_lo);
+            hout[nb][2 * t + half] = f;
+        }
+    };
+    constexpr bool DEFER = (MODE == MODE_HIDDEN || MODE == MODE_LINEAR);
+    constexpr int E0 = KS >= 8 ? 2 : 1, E1 = KS >= 8 ? 6 : (KS - 1);
+    static_for<0, NT>([&](auto ot_c) {
+        constexpr int ot = decltype(ot_c)::value;
+        constexpr int cur = ot & 1;
         X16_T(const unsigned long long s0 = x16_now();)
         {
             // acc = bias, broadcast over the samples, by ONE extra MFMA (hi/lo split keeps ~16 mantissa bits):
@@ -273,13 +321,12 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
             for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
             const f32x16 binit = X16<PREC>::mfma(bf, ones, zero);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = binit;
+            for (int nb = 0; nb < NB; ++nb) acc[cur][nb] = binit;
         }
         X16_T(const unsigned long long s1 = x16_now(); const unsigned long long rv0 = ws.t_rv;)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int p = ot * KS + ks;  // compile-time after unrolling
-            const frag a_cur = ws.template next<LATE, MODE == MODE_COMPOSITE, NT * KS>(p);
+        static_for<0, KS>([&](auto ks_c) {
+            constexpr int ks = decltype(ks_c)::value;
+            const frag a_cur = ws.template next<LATE, MODE == MODE_COMPOSITE, NT * KS, ot * KS + ks>();
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 frag b;
@@ -289,29 +336,24 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
                 } else {
                     b = hin[nb][ks >= KPE ? ks - KPE : 0];
                 }
-                acc[nb] = X16<PREC>::mfma(a_cur, b, acc[nb]);
+                acc[cur][nb] = X16<PREC>::mfma(a_cur, b, acc[cur][nb]);
             }
-        }
+            if (DEFER && ot > 0 && ks == E0) finish_half(ot - 1, 0);
+            if (DEFER && ot > 0 && ks == E1) finish_half(ot - 1, 1);
+        });
         X16_T(const unsigned long long s2 = x16_now();)
+        if (DEFER && ot == NT - 1) {
+            finish_half(ot, 0);
+            finish_half(ot, 1);
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            if (MODE == MODE_HIDDEN || MODE == MODE_LINEAR) {
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = acc[nb][r];
-                frag f0 = X16<PREC>::pack(v), f1 = X16<PREC>::pack(v + 8);
-                if (MODE == MODE_HIDDEN) {
-                    f0 = X16<PREC>::relu(f0, relu_lo);
-                    f1 = X16<PREC>::relu(f1, relu_lo);
-                }
-                hout[nb][2 * ot + 0] = f0;
-                hout[nb][2 * ot + 1] = f1;
-            } else if (MODE == MODE_DENSITY) {
-                aux[nb] = acc[nb][0];  // row 0 of the tile, valid on lanes with h == 0
-            } else {
+            if (MODE == MODE_DENSITY) {
+                aux[nb] = acc[cur][nb][0];  // row 0 of the tile, valid on lanes with h == 0
+            } else if (MODE == MODE_COMPOSITE) {
                 // weighted RGB_layer_1 activations; two tiles (32 values) feed one butterfly over the samples
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[nb][(ot & 1) * 16 + r] = fmaxf(acc[nb][r], 0.0f) * aux[nb];
+                for (int r = 0; r < 16; ++r) red[nb][(ot & 1) * 16 + r] = fmaxf(acc[cur][nb][r], 0.0f) * aux[nb];
                 if (ot & 1) {
                     float s = butterfly32(red[nb], c);
                     // bit-reversed lane index = which of the 32 reduced values this lane ended up with
@@ -327,7 +369,7 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
                   ws.tl[5 + 2 * (ws.tile_no - 20)] = (float)(s2 & 0xFFFFFF);
               }
               ++ws.tile_no;)
-    }
+    });
 }
 
 template <int PREC, int NB, int WAVES, bool LATE>
@@ -342,7 +384,7 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
     WeightStream<PREC, WAVES> ws;
     ws.gsrc = packed + (size_t)wave * WeightStream<PREC, WAVES>::PPW * X16_PIECE + lane * 16;
     ws.ring = lds;
-    ws.base = lds + lane * 16;
+    ws.lds_addr0 = (unsigned)(size_t)(LDS_AS unsigned char*)lds + lane * 16;
     ws.wave = wave;
     ws.prologue_issue();  // the sampler / encoder below runs under these loads
     // per-wave LDS copy of the PE fragments for the skip stage: NB*4 lane-linear 1 KiB pieces
