@@ -128,6 +128,9 @@ struct X16<N3DT_F16> {
 #ifndef X16_DEPTH
 #define X16_DEPTH 2
 #endif
+#ifndef X16_DEFER
+#define X16_DEFER 0
+#endif
 #define X16_NBUF 3
 #define X16_CHUNK_BYTES (X16_CH * X16_PIECE)
 
@@ -234,16 +237,23 @@ struct WeightStream {
     }
 };
 
-// positional-encoding channel `ch` (0..63) via v_sin_f32 on a two-term phase in revolutions
-__device__ __forceinline__ float pe_fast(const float p[3], const float rh[3], const float rl[3], int ch) {
-    if (ch < 3) return ch == 0 ? p[0] : (ch == 1 ? p[1] : p[2]);
-    if (ch >= N3DT_PE_DIM) return 0.0f;
-    const int k = (ch - 3) / 6, w = (ch - 3) % 6, dim = w % 3;
-    const float hi = dim == 0 ? rh[0] : (dim == 1 ? rh[1] : rh[2]);
-    const float lo = dim == 0 ? rl[0] : (dim == 1 ? rl[1] : rl[2]);
+// positional-encoding channel `ch` (0..63) via v_sin_f32 on a two-term phase in revolutions.  The three
+// coordinates travel as separate scalars and are picked with selects: with float[3] arguments hipcc turned the
+// runtime `dim` into an index into a private-memory copy (28 B/lane of scratch, 117 MB of traffic per launch).
+__device__ __forceinline__ float pick3(const int d, const float a, const float b, const float c) {
+    const float ab = d == 0 ? a : b;
+    return d == 2 ? c : ab;
+}
+__device__ __forceinline__ float pe_fast(const float p0, const float p1, const float p2, const float h0, const float h1,
+                                         const float h2, const float l0, const float l1, const float l2, const int ch) {
+    const int cc = ch < 3 ? 0 : ch - 3;
+    const int k = cc / 6, w = cc % 6, dim = w >= 3 ? w - 3 : w;
     const float sc = (float)(1 << k);
-    float r = __builtin_amdgcn_fractf(hi * sc) + lo * sc + (w >= 3 ? 0.25f : 0.0f);  // cos x = sin(x + pi/2)
-    return __builtin_amdgcn_sinf(r);
+    const float hi = pick3(dim, h0, h1, h2), lo = pick3(dim, l0, l1, l2);
+    const float r = __builtin_amdgcn_fractf(hi * sc) + lo * sc + (w >= 3 ? 0.25f : 0.0f);  // cos x = sin(x + pi/2)
+    const float sv = __builtin_amdgcn_sinf(r);
+    const float raw = pick3(ch, p0, p1, p2);
+    return ch < 3 ? raw : (ch >= N3DT_PE_DIM ? 0.0f : sv);
 }
 
 enum { MODE_HIDDEN = 0, MODE_LINEAR = 1, MODE_DENSITY = 2, MODE_COMPOSITE = 3 };
@@ -293,23 +303,25 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
     float bias_cur = bias[c];
     // Two accumulator sets: tile ot accumulates into acc[ot & 1] while the epilogue of tile ot-1 (pack to 16 bit,
     // ReLU) is placed between this tile's MFMAs -- VALU work issues under the matrix pipe instead of after it.
+    // X16_DEFER=1 measured perf-neutral (the wave is not VALU-bound in its epilogue) and costs 12 VGPRs: off by default
+    constexpr bool PACKS = (MODE == MODE_HIDDEN || MODE == MODE_LINEAR);
+    constexpr bool DEFER = PACKS && X16_DEFER;
     f32x16 acc[2][NB];
     auto finish_half = [&](const int t, const int half) {  // registers 8*half .. 8*half+7 of tile t -> k-step 2t+half
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             float v[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = acc[t & 1][nb][8 * half + r];
+            for (int r = 0; r < 8; ++r) v[r] = acc[DEFER ? (t & 1) : 0][nb][8 * half + r];
             frag f = X16<PREC>::pack(v);
             if (MODE == MODE_HIDDEN) f = X16<PREC>::relu(f, relu_lo);
             hout[nb][2 * t + half] = f;
         }
     };
-    constexpr bool DEFER = (MODE == MODE_HIDDEN || MODE == MODE_LINEAR);
     constexpr int E0 = KS >= 8 ? 2 : 1, E1 = KS >= 8 ? 6 : (KS - 1);
     static_for<0, NT>([&](auto ot_c) {
         constexpr int ot = decltype(ot_c)::value;
-        constexpr int cur = ot & 1;
+        constexpr int cur = DEFER ? (ot & 1) : 0;
         X16_T(const unsigned long long s0 = x16_now();)
         {
             // acc = bias, broadcast over the samples, by ONE extra MFMA (hi/lo split keeps ~16 mantissa bits):
@@ -342,7 +354,7 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
             if (DEFER && ot > 0 && ks == E1) finish_half(ot - 1, 1);
         });
         X16_T(const unsigned long long s2 = x16_now();)
-        if (DEFER && ot == NT - 1) {
+        if (PACKS && (!DEFER || ot == NT - 1)) {
             finish_half(ot, 0);
             finish_half(ot, 1);
         }
@@ -423,7 +435,9 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
         for (int ks = 0; ks < 4; ++ks) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = pe_fast(p, rh, rl, 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3));
+            for (int j = 0; j < 8; ++j)
+                v[j] = pe_fast(p[0], p[1], p[2], rh[0], rh[1], rh[2], rl[0], rl[1], rl[2],
+                               32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3));
             pe[nb][ks] = X16<PREC>::pack(v);
             *reinterpret_cast<frag*>(pe_lds + (nb * 4 + ks) * X16_PIECE) = pe[nb][ks];
         }
