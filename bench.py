@@ -38,7 +38,7 @@ def bench_train(args, net, opt, d, dev, world, rank):
     import torch
     import torch.distributed as dist
     from n3dt import parallel
-    from n3dt.train import data_losses, disk_mask
+    from n3dt.train import fused_data_losses as data_losses, disk_mask
     B = d["batch_xy"].shape[0]
     net.precision = "fp32"
     optim = torch.optim.Adam(net.parameters(), lr=1e-4)

@@ -183,6 +183,17 @@ int n3dt_neural_render_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p,
                            const float* featmap, const float* d_img, const void* saved, size_t saved_bytes,
                            float* d_featmap, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fused loss tail -----------------------------------------------------------------
+ * The three MSE data terms of the reference's loss (Utils/HeadNeRFLossUtils.py:125-146: bg_loss, head_loss,
+ * nonhead_loss, including its nan_to_num) in one pass, and their gradient in one more; replaces three boolean-mask
+ * gathers.  merge_img, gt [B,3,P,P]; bg_img [1,3,P,P]; mask [B,1,P,P] (head where >= 0.5); pixels = P*P.
+ * n3dt_loss_fwd writes terms[3] = {bg, head, nonhead} and keeps its sums/counts in acc[6] for n3dt_loss_bwd, which
+ * takes the upstream gradients g[3] of the three terms and writes d_merge [B,3,P,P] and d_bg [1,3,P,P]. */
+int n3dt_loss_fwd(int batch, int pixels, const float* merge_img, const float* bg_img, const float* gt, const float* mask,
+                  float bg_value, float* acc, float* terms, void* stream);
+int n3dt_loss_bwd(int batch, int pixels, const float* merge_img, const float* bg_img, const float* gt, const float* mask,
+                  float bg_value, const float* acc, const float* g, float* d_merge, float* d_bg, void* stream);
+
 /* [C, N_r] (NCHW parameter) -> [N_r, C]; used to feed bg_featmap to the renderer */
 int n3dt_chw_to_hwc(int C, int n, const float* src, float* dst, void* stream);
 

@@ -27,6 +27,9 @@ void n3dt_launch_train_fwd(const N3dtGeom*, const N3dtMlpParams*, const float*, 
 void n3dt_launch_train_bwd(const N3dtGeom*, const N3dtMlpParams*, const N3dtMlpGrads*, const float*, const float*, const float*,
                            const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*,
                            const float*, const float*, const float*, const float*, const float*, float*, float*, float*, hipStream_t);
+void n3dt_launch_loss_fwd(int, int, const float*, const float*, const float*, const float*, float, float*, float*, hipStream_t);
+void n3dt_launch_loss_bwd(int, int, const float*, const float*, const float*, const float*, float, const float*, const float*, float*,
+                          float*, hipStream_t);
 size_t n3dt_nr_train_saved_floats(const N3dtGeom*, int);
 size_t n3dt_nr_train_ws_floats(const N3dtGeom*, int);
 void n3dt_launch_nr_train_fwd(const N3dtGeom*, int, const N3dtRenderParams*, const float*, float*, float*, float*, hipStream_t);
@@ -299,4 +302,19 @@ extern "C" int n3dt_neural_render_bwd(const N3dtGeom* g, int nb, const N3dtRende
     if (workspace_bytes < n3dt_neural_render_train_workspace_bytes(g, nb)) return fail(N3DT_EWORKSPACE, "neural render workspace too small");
     n3dt_launch_nr_bwd(g, nb, p, grads, featmap, d_img, (const float*)saved, d_featmap, (float*)workspace, (hipStream_t)stream);
     return check_hip("n3dt_neural_render_bwd");
+}
+
+extern "C" int n3dt_loss_fwd(int batch, int pixels, const float* merge_img, const float* bg_img, const float* gt, const float* mask,
+                             float bg_value, float* acc, float* terms, void* stream) {
+    if (batch < 1 || pixels < 1 || !merge_img || !bg_img || !gt || !mask || !acc || !terms) return fail(N3DT_EINVAL, "n3dt_loss_fwd: bad argument");
+    n3dt_launch_loss_fwd(batch, pixels, merge_img, bg_img, gt, mask, bg_value, acc, terms, (hipStream_t)stream);
+    return check_hip("n3dt_loss_fwd");
+}
+
+extern "C" int n3dt_loss_bwd(int batch, int pixels, const float* merge_img, const float* bg_img, const float* gt, const float* mask,
+                             float bg_value, const float* acc, const float* g, float* d_merge, float* d_bg, void* stream) {
+    if (batch < 1 || pixels < 1 || !merge_img || !bg_img || !gt || !mask || !acc || !g || !d_merge || !d_bg)
+        return fail(N3DT_EINVAL, "n3dt_loss_bwd: bad argument");
+    n3dt_launch_loss_bwd(batch, pixels, merge_img, bg_img, gt, mask, bg_value, acc, g, d_merge, d_bg, (hipStream_t)stream);
+    return check_hip("n3dt_loss_bwd");
 }

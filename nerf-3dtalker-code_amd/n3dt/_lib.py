@@ -47,7 +47,7 @@ EXPORTS = [
     "n3dt_neural_render_fwd", "n3dt_chw_to_hwc", "n3dt_prof_enable", "n3dt_prof_collect",
     "n3dt_render_train_saved_bytes", "n3dt_render_train_workspace_bytes", "n3dt_render_train_fwd", "n3dt_render_bwd",
     "n3dt_neural_render_train_saved_bytes", "n3dt_neural_render_train_workspace_bytes",
-    "n3dt_neural_render_train_fwd", "n3dt_neural_render_bwd",
+    "n3dt_neural_render_train_fwd", "n3dt_neural_render_bwd", "n3dt_loss_fwd", "n3dt_loss_bwd",
 ]
 
 _LIB = None
@@ -99,6 +99,10 @@ def lib():
     L.n3dt_neural_render_train_fwd.argtypes = [gp, ci, rp, vp, vp, vp, sz, vp, sz, vp]
     L.n3dt_neural_render_bwd.restype = ci
     L.n3dt_neural_render_bwd.argtypes = [gp, ci, rp, rp, vp, vp, vp, sz, vp, vp, sz, vp]
+    L.n3dt_loss_fwd.restype = ci
+    L.n3dt_loss_fwd.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp]
+    L.n3dt_loss_bwd.restype = ci
+    L.n3dt_loss_bwd.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, vp]
     L.n3dt_prof_enable.restype = ci
     L.n3dt_prof_enable.argtypes = [ci]
     L.n3dt_prof_collect.restype = ci

@@ -30,6 +30,43 @@ def data_losses(coarse, gt_rgb, mask, bg_value=1.0):
     return {"bg_loss": bg_loss, "head_loss": head_loss, "nonhead_loss": nonhead_loss}
 
 
+class _FusedDataLoss(torch.autograd.Function):
+    """bg / head / nonhead MSE terms in one pass over the images (n3dt_loss_fwd / n3dt_loss_bwd)."""
+
+    @staticmethod
+    def forward(ctx, merge_img, bg_img, gt_rgb, mask, bg_value):
+        import ctypes
+        from . import ops
+        from ._lib import lib, check
+        B, _, P, _ = merge_img.shape
+        m, b, g, k = (t.detach().float().contiguous() for t in (merge_img, bg_img, gt_rgb, mask))
+        acc = torch.empty(6, dtype=torch.float32, device=m.device)
+        terms = torch.empty(3, dtype=torch.float32, device=m.device)
+        check(lib().n3dt_loss_fwd(B, P * P, ops._ptr(m), ops._ptr(b), ops._ptr(g), ops._ptr(k), ctypes.c_float(bg_value),
+                                  ops._ptr(acc), ops._ptr(terms), ops._stream()), "n3dt_loss_fwd")
+        ctx.keep, ctx.bg_value = (m, b, g, k, acc), bg_value
+        return terms
+
+    @staticmethod
+    def backward(ctx, g_terms):
+        import ctypes
+        from . import ops
+        from ._lib import lib, check
+        m, b, g, k, acc = ctx.keep
+        B, _, P, _ = m.shape
+        d_m, d_b = torch.empty_like(m), torch.empty_like(b)
+        check(lib().n3dt_loss_bwd(B, P * P, ops._ptr(m), ops._ptr(b), ops._ptr(g), ops._ptr(k), ctypes.c_float(ctx.bg_value),
+                                  ops._ptr(acc), ops._ptr(g_terms.float().contiguous()), ops._ptr(d_m), ops._ptr(d_b),
+                                  ops._stream()), "n3dt_loss_bwd")
+        return d_m, d_b, None, None, None
+
+
+def fused_data_losses(coarse, gt_rgb, mask, bg_value=1.0):
+    """Same three terms as data_losses(), computed by the fused HIP loss tail (no host synchronisation)."""
+    t = _FusedDataLoss.apply(coarse["merge_img"], coarse["bg_img"], gt_rgb, mask, bg_value)
+    return {"bg_loss": t[0], "head_loss": t[1], "nonhead_loss": t[2]}
+
+
 def make_optimizer(net, lr=1e-4):
     """Adam + StepLR as the reference builds them (talker_trainer.py:722-727)."""
     opt = torch.optim.Adam(net.parameters(), lr=lr)
@@ -37,12 +74,12 @@ def make_optimizer(net, lr=1e-4):
     return opt, sched
 
 
-def train_step(net, optimizer, inputs, gt_rgb, mask, t_rand=None, extra_optimizers=()):
+def train_step(net, optimizer, inputs, gt_rgb, mask, t_rand=None, extra_optimizers=(), fused_loss=True):
     """One reference-shaped step: forward("train") -> losses -> zero_grad -> backward -> step."""
     pred = net("train", inputs["batch_xy"], inputs["batch_uv"], inputs["audiostyle"], bg_code=None,
                shape_code=inputs["shape_code"], appea_code=inputs["appea_code"], batch_Rmats=inputs["batch_Rmats"],
                batch_Tvecs=inputs["batch_Tvecs"], batch_inv_inmats=inputs["batch_inv_inmats"], t_rand=t_rand)
-    terms = data_losses(pred["coarse_dict"], gt_rgb, mask)
+    terms = (fused_data_losses if fused_loss else data_losses)(pred["coarse_dict"], gt_rgb, mask)
     total = terms["bg_loss"] + terms["head_loss"] + terms["nonhead_loss"]
     for o in extra_optimizers:
         o.zero_grad()

@@ -148,3 +148,26 @@ def test_loss_decreases_over_a_few_steps():
         _, terms = train_step(net, optim, d, gt, mask, t_rand=t_rand)
         losses.append(float(terms["total_loss"].detach()))
     assert losses[-1] < losses[0]
+
+
+def test_fused_loss_tail_matches_the_torch_terms():
+    """one-pass masked-MSE terms and their gradient vs the plain-PyTorch restatement of
+    Utils/HeadNeRFLossUtils.py:125-146, including nan_to_num on a poisoned pixel."""
+    from n3dt.train import data_losses, fused_data_losses, disk_mask
+    gen = torch.Generator().manual_seed(2)
+    B, P = 3, 32
+    merge = torch.rand(B, 3, P, P, generator=gen).to(dev())
+    merge[1, 2, 5, 7] = float("nan")
+    bg = torch.rand(1, 3, P, P, generator=gen).to(dev())
+    gt = torch.rand(B, 3, P, P, generator=gen).to(dev())
+    mask = disk_mask(B, P).to(dev())
+    outs = []
+    for fn in (data_losses, fused_data_losses):
+        m = merge.clone().requires_grad_(True)
+        b = bg.clone().requires_grad_(True)
+        t = fn({"merge_img": m, "bg_img": b}, gt, mask)
+        (1.0 * t["bg_loss"] + 2.0 * t["head_loss"] + 3.0 * t["nonhead_loss"]).backward()
+        outs.append(([float(t[k].detach()) for k in ("bg_loss", "head_loss", "nonhead_loss")], m.grad, b.grad))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-6)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-9)

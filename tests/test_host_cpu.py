@@ -88,3 +88,20 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(root, f)).read()
                 assert "oracle" not in text.replace("# oracle", ""), "%s mentions the oracle" % f
+
+
+def test_orbit_cameras_look_at_the_origin():
+    """RenderUtils: 45 orbit cameras, orthonormal c2w rotations whose forward axis points at the origin."""
+    from n3dt import BaseOptions
+    from n3dt.render_utils import RenderUtils
+    ru = RenderUtils(45, torch.device("cpu"), BaseOptions())
+    assert ru.ray_xy.shape == (1, 2, 1024) and ru.Rmats.shape == (45, 3, 3) and ru.Tvecs.shape == (45, 3, 1)
+    eye = torch.eye(3).expand(45, 3, 3)
+    torch.testing.assert_close(ru.Rmats @ ru.Rmats.transpose(1, 2), eye, atol=1e-5, rtol=0)
+    fwd = ru.Rmats[:, :, 2]
+    t = ru.Tvecs[:, :, 0]
+    torch.testing.assert_close(fwd, -t / t.norm(dim=1, keepdim=True), atol=1e-5, rtol=0)
+    assert torch.allclose(t[:, 2], torch.full((45,), 12.0)) and torch.allclose(t[:, :2].norm(dim=1), torch.full((45,), 5.3), atol=1e-5)
+    # first and last views coincide (0 and 360 degrees), like np.linspace(0, 360, view_num)
+    torch.testing.assert_close(ru.Tvecs[0], ru.Tvecs[-1], atol=1e-4, rtol=0)
+    assert torch.equal(ru.base_cam_info["batch_Rmats"][0], torch.diag(torch.tensor([1.0, -1.0, -1.0])))
