@@ -105,3 +105,22 @@ def test_orbit_cameras_look_at_the_origin():
     # first and last views coincide (0 and 360 degrees), like np.linspace(0, 360, view_num)
     torch.testing.assert_close(ru.Tvecs[0], ru.Tvecs[-1], atol=1e-4, rtol=0)
     assert torch.equal(ru.base_cam_info["batch_Rmats"][0], torch.diag(torch.tensor([1.0, -1.0, -1.0])))
+
+
+def test_checkpoint_round_trip_and_gaze_extension(tmp_path):
+    """Reference checkpoint layout {"para", "net", ...} saves, loads and extends for eye gaze."""
+    from n3dt import HeadNeRFNet, BaseOptions, synthetic as syn, checkpoint
+    opt = BaseOptions({"featmap_size": 32, "featmap_nc": 256, "pred_img_size": 256})
+    net = HeadNeRFNet(opt, False, False)
+    net.load_state_dict(syn.make_state_dict(opt, seed=5))
+    path = str(tmp_path / "epoch_0_ckpt.pth.tar")
+    checkpoint.save_checkpoint(path, net, opt, epoch=3)
+    net2, opt2 = checkpoint.build_from_checkpoint(path)
+    assert opt2.featmap_size == 32 and opt2.pred_img_size == 256
+    for (k, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert torch.equal(a, b), k
+    netg, _ = checkpoint.build_from_checkpoint(path, include_gaze=True, eye_gaze_dim=64)
+    w = netg.state_dict()["fg_CD_predictor.FeaExt_module_0.weight"]
+    assert w.shape[1] == 306 + 64 and float(w[:, 306:].abs().max()) == 0.0
+    skipped = checkpoint.load_ckpt(net2, {"fg_CD_predictor.RGB_layer_2.bias": torch.zeros(256), "bogus": torch.zeros(1)})
+    assert skipped == ["bogus"] and float(net2.state_dict()["fg_CD_predictor.RGB_layer_2.bias"].abs().max()) == 0.0
