@@ -309,7 +309,7 @@ class HeadNeRFNet(nn.Module):
         return hit[1]
 
     def render_features(self, batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
-                        t_rand=None, want_depth=False, want_weight=False, want_merge=True, precision=None):
+                        t_rand=None, want_depth=False, want_weight=False, want_merge=True, precision=None, merge_out=None):
         """Rays -> composited feature map (seams a1..a7).  Outputs are ray-major [B, N_r, C]."""
         prec = _lib.PRECISIONS[precision or self.precision]
         B, tv, n_r = batch_xy.size()
@@ -323,7 +323,7 @@ class HeadNeRFNet(nn.Module):
                              ops._f32c(batch_inv_inmats), ops._f32c(shape_code), ops._f32c(appea_code), audio,
                              None if t_rand is None else ops._f32c(t_rand),
                              self.neural_render.bg_featmap.detach().view(self.featmap_nc, -1) if want_merge else None,
-                             want_depth=want_depth, want_weight=want_weight, want_merge=want_merge)
+                             want_depth=want_depth, want_weight=want_weight, want_merge=want_merge, merge_out=merge_out)
         return out
 
     def _forward(self, for_train, batch_xy, batch_uv, audiostyle, bg_code, shape_code, appea_code, batch_Rmats,
@@ -343,11 +343,11 @@ class HeadNeRFNet(nn.Module):
             any(torch.is_tensor(t) and t.requires_grad for t in (audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs)))
         if needs_grad:
             return self._forward_train(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand)
-        out = self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
-                                   t_rand=t_rand, want_merge=True)
-        # the merged maps and the background map go through the 2-D renderer in one call (nb = B+1)
+        # the merged maps and the background map go through the 2-D renderer in one call (nb = B+1); the render
+        # kernel writes its merged maps straight into that batch
         maps = torch.empty(batch_size + 1, fs, fs, C, dtype=torch.float32, device=batch_xy.device)
-        maps[:batch_size] = out["merge_feat"].view(batch_size, fs, fs, C)
+        self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
+                             t_rand=t_rand, want_merge=True, merge_out=maps[:batch_size].view(batch_size, fs * fs, C))
         ops.chw_to_hwc(self.neural_render.bg_featmap.detach().view(C, fs * fs), C, fs * fs, maps[batch_size].view(fs * fs, C))
         imgs = self.neural_render.render_hwc(maps, self.precision)
         return {"coarse_dict": {"merge_img": imgs[:batch_size], "bg_img": imgs[batch_size:]}}
