@@ -41,6 +41,9 @@ def bench_train(args, net, opt, d, dev, world, rank):
     from n3dt.train import fused_data_losses as data_losses, disk_mask
     B = d["batch_xy"].shape[0]
     net.precision = "fp32"
+    tp = "bf16" if args.precision == "bf16" else "fp32"
+    net.train_precision = tp
+    net.neural_render.train_precision = tp
     optim = torch.optim.Adam(net.parameters(), lr=1e-4)
     gt = torch.full((B, 3, opt.pred_img_size, opt.pred_img_size), 0.5, device=dev)
     mask = disk_mask(B, opt.pred_img_size).to(dev)
@@ -80,7 +83,7 @@ def bench_train(args, net, opt, d, dev, world, rank):
             "metric": "trained frames/sec @512^2 x 64 samples/ray (fwd+bwd+Adam)", "value": world * B * args.steps / elapsed,
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32", "data": "synthetic",
+            "dtype": tp, "data": "synthetic",
             "config": {"workload": "cfg3: %d heads/GPU/step, 64x64 rays x 64 samples -> 512x512, 3 MSE terms, Adam" % B,
                        "parallelism": "frames sharded over %d rank(s), one flat gradient all-reduce per step" % world},
         }), flush=True)

@@ -146,8 +146,10 @@ int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, int precision, const N3dtR
                            float* img, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- training path (fwd -> loss -> backward) -----------------------------------
- * Exact fp32.  The forward keeps the per-layer activations in `saved` (caller-owned, sized by the
- * *_saved_bytes query) for the matching backward call; `workspace` is scratch.
+ * `precision` = N3DT_F32: exact fp32 (the mode the gradient-parity tests pin); N3DT_BF16: every matrix product
+ * on v_mfma_f32_32x32x16_bf16 with operands rounded to bf16 while staging (fp32 storage and accumulation), the
+ * rest identical.  The forward keeps the per-layer activations in `saved` (caller-owned, sized by the
+ * *_saved_bytes query) for the matching backward call, which must use the same precision; `workspace` is scratch.
  *
  * n3dt_render_train_fwd: same mathematics and outputs as n3dt_render_fwd (fg_feat, bg_alpha, depth?, merge_feat?).
  * n3dt_render_bwd: given dL/d(merge_feat) (and optionally dL/d(fg_feat), dL/d(bg_alpha), both nullable),
@@ -159,12 +161,12 @@ int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, int precision, const N3dtR
  *   used it) must then be the forward's inputs.  Pass NULL for all seven to skip that work. */
 size_t n3dt_render_train_saved_bytes(const N3dtGeom* g);
 size_t n3dt_render_train_workspace_bytes(const N3dtGeom* g);
-int n3dt_render_train_fwd(const N3dtGeom* g, const void* packed_mlp, const N3dtMlpParams* p,
+int n3dt_render_train_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, const N3dtMlpParams* p,
                           const float* xy, const float* R, const float* T, const float* Kinv,
                           const float* shape, const float* appea, const float* audio, const float* t_rand,
                           const float* bg_featmap, float* fg_feat, float* bg_alpha, float* depth, float* merge_feat,
                           void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream);
-int n3dt_render_bwd(const N3dtGeom* g, const N3dtMlpParams* p, const N3dtMlpGrads* grads,
+int n3dt_render_bwd(const N3dtGeom* g, int precision, const N3dtMlpParams* p, const N3dtMlpGrads* grads,
                     const float* shape, const float* appea, const float* audio, const float* bg_featmap,
                     const float* d_merge_feat, const float* d_fg_feat, const float* d_bg_alpha,
                     const void* saved, size_t saved_bytes,
@@ -177,9 +179,9 @@ int n3dt_render_bwd(const N3dtGeom* g, const N3dtMlpParams* p, const N3dtMlpGrad
  * NetWorks/PixelShuffleUpsample.py:36-45).  d_featmap [nb,fs,fs,C] is overwritten; parameter gradients accumulate. */
 size_t n3dt_neural_render_train_saved_bytes(const N3dtGeom* g, int nb);
 size_t n3dt_neural_render_train_workspace_bytes(const N3dtGeom* g, int nb);
-int n3dt_neural_render_train_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap, float* img,
+int n3dt_neural_render_train_fwd(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const float* featmap, float* img,
                                  void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream);
-int n3dt_neural_render_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N3dtRenderGrads* grads,
+int n3dt_neural_render_bwd(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const N3dtRenderGrads* grads,
                            const float* featmap, const float* d_img, const void* saved, size_t saved_bytes,
                            float* d_featmap, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -40,3 +40,5 @@ struct Gemm32 {
 };
 
 void n3dt_gemm32(const Gemm32& g, hipStream_t stream);
+// bf16 != 0: same product on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 while staging, fp32 accumulate/output)
+void n3dt_gemm(const Gemm32& g, int bf16, hipStream_t stream);

@@ -23,18 +23,18 @@ size_t n3dt_train_saved_floats(const N3dtGeom*);
 size_t n3dt_train_ws_floats(const N3dtGeom*);
 void n3dt_launch_train_fwd(const N3dtGeom*, const N3dtMlpParams*, const float*, const float*, const float*, const float*, const float*,
                            const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, float*,
-                           float*, hipStream_t);
+                           float*, int, hipStream_t);
 void n3dt_launch_train_bwd(const N3dtGeom*, const N3dtMlpParams*, const N3dtMlpGrads*, const float*, const float*, const float*,
                            const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*,
-                           const float*, const float*, const float*, const float*, const float*, float*, float*, float*, hipStream_t);
+                           const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, hipStream_t);
 void n3dt_launch_loss_fwd(int, int, const float*, const float*, const float*, const float*, float, float*, float*, hipStream_t);
 void n3dt_launch_loss_bwd(int, int, const float*, const float*, const float*, const float*, float, const float*, const float*, float*,
                           float*, hipStream_t);
 size_t n3dt_nr_train_saved_floats(const N3dtGeom*, int);
 size_t n3dt_nr_train_ws_floats(const N3dtGeom*, int);
-void n3dt_launch_nr_train_fwd(const N3dtGeom*, int, const N3dtRenderParams*, const float*, float*, float*, float*, hipStream_t);
+void n3dt_launch_nr_train_fwd(const N3dtGeom*, int, const N3dtRenderParams*, const float*, float*, float*, float*, int, hipStream_t);
 void n3dt_launch_nr_bwd(const N3dtGeom*, int, const N3dtRenderParams*, const N3dtRenderGrads*, const float*, const float*, const float*,
-                        float*, float*, hipStream_t);
+                        float*, float*, int, hipStream_t);
 void n3dt_launch_neural_render(const N3dtGeom*, int, int, const N3dtRenderParams*, const float*, float*, float*, hipStream_t);
 }
 
@@ -219,13 +219,14 @@ extern "C" size_t n3dt_render_train_workspace_bytes(const N3dtGeom* g) {
     return n3dt_train_ws_floats(g) * sizeof(float);
 }
 
-extern "C" int n3dt_render_train_fwd(const N3dtGeom* g, const void* packed_mlp, const N3dtMlpParams* p, const float* xy, const float* R,
+extern "C" int n3dt_render_train_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, const N3dtMlpParams* p, const float* xy, const float* R,
                                      const float* T, const float* Kinv, const float* shape, const float* appea, const float* audio,
                                      const float* t_rand, const float* bg_featmap, float* fg_feat, float* bg_alpha, float* depth,
                                      float* merge_feat, void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
                                      void* stream) {
     int rc = check_train_geom(g);
     if (rc) return rc;
+    if (precision != N3DT_F32 && precision != N3DT_BF16) return fail(N3DT_EINVAL, "training precision must be N3DT_F32 or N3DT_BF16");
     if (!packed_mlp || !p || !xy || !R || !T || !Kinv || !shape || !appea || !fg_feat || !saved || !workspace)
         return fail(N3DT_EINVAL, "n3dt_render_train_fwd: NULL argument");
     if (g->audio_dim > 0 && !audio) return fail(N3DT_EINVAL, "n3dt_render_train_fwd: audio is NULL but audio_dim > 0");
@@ -235,11 +236,11 @@ extern "C" int n3dt_render_train_fwd(const N3dtGeom* g, const void* packed_mlp, 
     // the fp32 tail (W2^T, b2) sits at the same place in a packed buffer of any precision given to us as F32-packed
     const float* tail = (const float*)((const unsigned char*)packed_mlp + n3dt_packed_tail_offset(N3DT_F32));
     n3dt_launch_train_fwd(g, p, tail, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap, fg_feat, bg_alpha, depth, merge_feat,
-                          (float*)saved, (float*)workspace, (hipStream_t)stream);
+                          (float*)saved, (float*)workspace, precision == N3DT_BF16, (hipStream_t)stream);
     return check_hip("n3dt_render_train_fwd");
 }
 
-extern "C" int n3dt_render_bwd(const N3dtGeom* g, const N3dtMlpParams* p, const N3dtMlpGrads* grads, const float* shape,
+extern "C" int n3dt_render_bwd(const N3dtGeom* g, int precision, const N3dtMlpParams* p, const N3dtMlpGrads* grads, const float* shape,
                                const float* appea, const float* audio, const float* bg_featmap, const float* d_merge_feat,
                                const float* d_fg_feat, const float* d_bg_alpha, const void* saved, size_t saved_bytes,
                                float* d_bg_featmap, float* d_shape, float* d_appea, float* d_audio, const float* xy, const float* R,
@@ -247,6 +248,7 @@ extern "C" int n3dt_render_bwd(const N3dtGeom* g, const N3dtMlpParams* p, const 
                                size_t workspace_bytes, void* stream) {
     int rc = check_train_geom(g);
     if (rc) return rc;
+    if (precision != N3DT_F32 && precision != N3DT_BF16) return fail(N3DT_EINVAL, "training precision must be N3DT_F32 or N3DT_BF16");
     if (!p || !grads || !shape || !appea || !saved || !workspace) return fail(N3DT_EINVAL, "n3dt_render_bwd: NULL argument");
     if (!d_merge_feat && !d_fg_feat && !d_bg_alpha) return fail(N3DT_EINVAL, "n3dt_render_bwd: no incoming gradient");
     if (d_merge_feat && !bg_featmap) return fail(N3DT_EINVAL, "n3dt_render_bwd: d_merge_feat needs bg_featmap");
@@ -258,7 +260,7 @@ extern "C" int n3dt_render_bwd(const N3dtGeom* g, const N3dtMlpParams* p, const 
     if ((d_R || d_T) && (!xy || !R || !T || !Kinv)) return fail(N3DT_EINVAL, "n3dt_render_bwd: camera gradients need xy, R, T, Kinv");
     n3dt_launch_train_bwd(g, p, grads, shape, appea, audio, bg_featmap, d_merge_feat, d_fg_feat, d_bg_alpha, (const float*)saved,
                           d_bg_featmap, d_shape, d_appea, d_audio, xy, R, T, Kinv, t_rand, d_R, d_T, (float*)workspace,
-                          (hipStream_t)stream);
+                          precision == N3DT_BF16, (hipStream_t)stream);
     return check_hip("n3dt_render_bwd");
 }
 
@@ -280,18 +282,18 @@ extern "C" size_t n3dt_neural_render_train_workspace_bytes(const N3dtGeom* g, in
     return n3dt_nr_train_ws_floats(g, nb) * sizeof(float);
 }
 
-extern "C" int n3dt_neural_render_train_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap, float* img,
+extern "C" int n3dt_neural_render_train_fwd(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const float* featmap, float* img,
                                             void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_nr(g, nb);
     if (rc) return rc;
     if (!p || !featmap || !img || !saved || !workspace) return fail(N3DT_EINVAL, "n3dt_neural_render_train_fwd: NULL argument");
     if (saved_bytes < n3dt_neural_render_train_saved_bytes(g, nb)) return fail(N3DT_EWORKSPACE, "neural render saved buffer too small");
     if (workspace_bytes < n3dt_neural_render_train_workspace_bytes(g, nb)) return fail(N3DT_EWORKSPACE, "neural render workspace too small");
-    n3dt_launch_nr_train_fwd(g, nb, p, featmap, img, (float*)saved, (float*)workspace, (hipStream_t)stream);
+    n3dt_launch_nr_train_fwd(g, nb, p, featmap, img, (float*)saved, (float*)workspace, precision == N3DT_BF16, (hipStream_t)stream);
     return check_hip("n3dt_neural_render_train_fwd");
 }
 
-extern "C" int n3dt_neural_render_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N3dtRenderGrads* grads,
+extern "C" int n3dt_neural_render_bwd(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const N3dtRenderGrads* grads,
                                       const float* featmap, const float* d_img, const void* saved, size_t saved_bytes, float* d_featmap,
                                       void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_nr(g, nb);
@@ -300,7 +302,7 @@ extern "C" int n3dt_neural_render_bwd(const N3dtGeom* g, int nb, const N3dtRende
         return fail(N3DT_EINVAL, "n3dt_neural_render_bwd: NULL argument");
     if (saved_bytes < n3dt_neural_render_train_saved_bytes(g, nb)) return fail(N3DT_EWORKSPACE, "neural render saved buffer too small");
     if (workspace_bytes < n3dt_neural_render_train_workspace_bytes(g, nb)) return fail(N3DT_EWORKSPACE, "neural render workspace too small");
-    n3dt_launch_nr_bwd(g, nb, p, grads, featmap, d_img, (const float*)saved, d_featmap, (float*)workspace, (hipStream_t)stream);
+    n3dt_launch_nr_bwd(g, nb, p, grads, featmap, d_img, (const float*)saved, d_featmap, (float*)workspace, precision == N3DT_BF16, (hipStream_t)stream);
     return check_hip("n3dt_neural_render_bwd");
 }
 

@@ -384,18 +384,48 @@ __global__ void train_camera_bwd_kernel(N3dtGeom g, const float* __restrict__ xy
     }
 }
 
-// out[f][n] = sum over the rows of frame f of X[m][n]   (per-frame bias gradients); grid (ceil(N/256), chunks, B)
+// out[f][n] += sum over the rows of frame f of X[m][n]   (bias gradients; per frame for the folded biases).
+// One thread = 4 adjacent columns x a 256-row chunk, 8 independent float4 loads in flight; grid (row chunks, frames).
+#define CS_ROWS 256
 __global__ void train_colsum_kernel(const float* __restrict__ X, long ldx, int rows_per_frame, int N, float* __restrict__ out,
                                     long ldo) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const int f = blockIdx.z;
-    const int per = (rows_per_frame + gridDim.y - 1) / gridDim.y;
-    const int r0 = blockIdx.y * per, r1 = min(rows_per_frame, r0 + per);
-    const float* base = X + ((size_t)f * rows_per_frame) * ldx + n;
-    float acc = 0.0f;
-    for (int r = r0; r < r1; ++r) acc += base[(size_t)r * ldx];
-    atomicAdd(&out[(size_t)f * ldo + n], acc);
+    const int n4 = (N + 3) / 4;
+    const int t = threadIdx.x;
+    if (t >= n4) return;
+    const int f = blockIdx.y;
+    const int r0 = blockIdx.x * CS_ROWS, r1 = min(rows_per_frame, r0 + CS_ROWS);
+    const float* base = X + ((size_t)f * rows_per_frame) * ldx + 4 * t;
+    const bool vec = (4 * t + 4 <= N) && ((ldx & 3) == 0) && ((((size_t)base) & 15) == 0);
+    f32x4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+        int r = r0;
+        for (; r + 8 <= r1; r += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (size_t)(r + u) * ldx);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u & 3] += v[u];
+        }
+        for (; r < r1; ++r) acc[0] += *reinterpret_cast<const f32x4*>(base + (size_t)r * ldx);
+    } else {
+        for (int r = r0; r < r1; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * t + j < N) acc[0][j] += base[(size_t)r * ldx + j];
+    }
+    const f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (4 * t + j < N) atomicAdd(&out[(size_t)f * ldo + 4 * t + j], s[j]);
+}
+
+static void launch_colsum(const float* X, long ldx, int rows_per_frame, int frames, int N, float* out, long ldo, hipStream_t s) {
+    const int n4 = (N + 3) / 4;
+    const int threads = ((n4 + 63) / 64) * 64;
+    hipLaunchKernelGGL(train_colsum_kernel, dim3((rows_per_frame + CS_ROWS - 1) / CS_ROWS, frames), dim3(threads), 0, s, X, ldx,
+                       rows_per_frame, N, out, ldo);
 }
 
 // latent folding backward.  dfold[f] holds d b0'[384] (offset 0), d b5' (offset 5*384), d brgb1' (offset of stage 10).
@@ -438,7 +468,8 @@ __global__ void train_fold_bwd_kernel(N3dtMlpParams p, N3dtMlpGrads gp, int S, i
 }
 
 // scatter the packed gradients back: dW5[:,0:63] += dW5'[:,0:63]; dW5[:,63+S:] += dW5'[:,64:]; dWr0 += dWc[0:384]; dwd += dWc[384]
-__global__ void train_unpack_grads_kernel(N3dtMlpGrads gp, int S, const float* __restrict__ dw5p, const float* __restrict__ dwc) {
+__global__ void train_unpack_grads_kernel(N3dtMlpGrads gp, int S, const float* __restrict__ dw5p, const float* __restrict__ dwc,
+                                          const float* __restrict__ dbc) {
     const int in5 = N3DT_PE_DIM + S + N3DT_HID;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 384 * 448) {
@@ -449,6 +480,10 @@ __global__ void train_unpack_grads_kernel(N3dtMlpGrads gp, int S, const float* _
     if (i < 385 * 384) {
         if (i < 384 * 384) gp.weight[9][i] += dwc[i];
         else gp.weight[8][i - 384 * 384] += dwc[i];
+    }
+    if (i < 385) {
+        if (i < 384) gp.bias[9][i] += dbc[i];
+        else gp.bias[8][0] += dbc[i];
     }
 }
 
@@ -489,7 +524,7 @@ static int split_for(long K) {
 extern "C" void n3dt_launch_train_fwd(const N3dtGeom* g, const N3dtMlpParams* p, const float* tail, const float* xy, const float* R,
                                       const float* T, const float* Kinv, const float* shape, const float* appea, const float* audio,
                                       const float* t_rand, const float* bg_featmap, float* fg_feat, float* bg_alpha, float* depth,
-                                      float* merge_feat, float* saved, float* ws, hipStream_t s) {
+                                      float* merge_feat, float* saved, float* ws, int bf16, hipStream_t s) {
     const TrainSaved sv = saved_layout(g);
     const TrainWs wl = ws_layout(g);
     const int P = g->batch * g->n_rays * g->n_samples, ppf = g->n_rays * g->n_samples;
@@ -507,23 +542,23 @@ extern "C" void n3dt_launch_train_fwd(const N3dtGeom* g, const N3dtMlpParams* p,
     {
         Gemm32 q = mk(P, 384, 63, cat5, 448, 0, p->weight[0], 63 + S + U, 0, hptr(0), hld(0));
         q.bias = fold + n3dt_bias_offset(0); q.bias_group_rows = ppf; q.bias_ld = N3DT_FOLD_STRIDE; q.act = G32_ACT_RELU;
-        n3dt_gemm32(q, s);
+        n3dt_gemm(q, bf16, s);
     }
     for (int l = 1; l < 8; ++l) {
         Gemm32 q = l == 5 ? mk(P, 384, 448, cat5, 448, 0, ws + wl.w5p, 448, 0, hptr(5), hld(5))
                           : mk(P, 384, 384, hptr(l - 1), hld(l - 1), 0, p->weight[l], 384, 0, hptr(l), hld(l));
         q.bias = fold + n3dt_bias_offset(l); q.bias_group_rows = ppf; q.bias_ld = N3DT_FOLD_STRIDE; q.act = G32_ACT_RELU;
-        n3dt_gemm32(q, s);
+        n3dt_gemm(q, bf16, s);
     }
     {   // RGB_layer_0 | density_module (models.py:78-79)
         Gemm32 q = mk(P, 385, 384, hptr(7), 384, 0, ws + wl.wc, 384, 0, saved + sv.xr, XR_LD);
         q.bias = ws + wl.bc;
-        n3dt_gemm32(q, s);
+        n3dt_gemm(q, bf16, s);
     }
     {   // RGB_layer_1 (+ folded appearance), relu (models.py:80-81)
         Gemm32 q = mk(P, 192, 384, saved + sv.xr, XR_LD, 0, p->weight[10], 384 + A, 0, saved + sv.g, 192);
         q.bias = fold + n3dt_bias_offset(10); q.bias_group_rows = ppf; q.bias_ld = N3DT_FOLD_STRIDE; q.act = G32_ACT_RELU;
-        n3dt_gemm32(q, s);
+        n3dt_gemm(q, bf16, s);
     }
     const long Rr = (long)g->batch * g->n_rays;
     hipLaunchKernelGGL(train_composite_fwd_kernel, dim3((unsigned)((Rr + 3) / 4)), dim3(256), 0, s, *g, saved + sv.xr, saved + sv.g,
@@ -535,7 +570,7 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
                                       const float* appea, const float* audio, const float* bg_featmap, const float* d_merge,
                                       const float* d_fg, const float* d_ba, const float* saved, float* d_bg_featmap, float* d_shape,
                                       float* d_appea, float* d_audio, const float* xy, const float* Rm, const float* Tv,
-                                      const float* Kinv, const float* t_rand, float* d_R, float* d_T, float* ws, hipStream_t s) {
+                                      const float* Kinv, const float* t_rand, float* d_R, float* d_T, float* ws, int bf16, hipStream_t s) {
     const TrainSaved sv = saved_layout(g);
     const TrainWs wl = ws_layout(g);
     const int P = g->batch * g->n_rays * g->n_samples, ppf = g->n_rays * g->n_samples;
@@ -552,8 +587,12 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
     // dha doubles as the [R][256] d_fg_total scratch before the MLP backward starts
     float* dfg_total = dha;
     (void)hipMemsetAsync(dfold, 0, sizeof(float) * (size_t)B * N3DT_FOLD_STRIDE, s);
+    // the workspace is scratch: rebuild the packed W5' / [Wr0; wd] here rather than trusting the forward's copy
+    hipLaunchKernelGGL(train_pack_kernel, dim3((385 * 384 + 384 * 448 + 255) / 256), dim3(256), 0, s, *p, S, ws + wl.w5p, ws + wl.wc,
+                       ws + wl.bc);
     (void)hipMemsetAsync(ws + wl.dw5p, 0, sizeof(float) * 384 * 448, s);
     (void)hipMemsetAsync(ws + wl.dwc, 0, sizeof(float) * 385 * 384, s);
+    (void)hipMemsetAsync(ws + wl.bc, 0, sizeof(float) * 385, s);  // re-used as the [d br0 | d bd] accumulator (Wc's bias is not needed in backward)
     if (d_shape) (void)hipMemsetAsync(d_shape, 0, sizeof(float) * (size_t)B * S, s);
     // ---- head: RGB_layer_2 once per ray + merge (models.py:82, HeadNeRFNet.py:103-112)
     hipLaunchKernelGGL(train_head_bwd_kernel, dim3((unsigned)Rr), dim3(256), 0, s, *g, p->weight[11], p->bias[11], bg_featmap, d_merge,
@@ -563,7 +602,7 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
     {   // dW2[256][192] += dfg_total^T Gray
         Gemm32 q = mk(256, 192, (int)Rr, dfg_total, 256, 1, saved + sv.ray, N3DT_PART_STRIDE, 1, gp->weight[11], 192);
         set_grad_split(q, Rr);
-        n3dt_gemm32(q, s);
+        n3dt_gemm(q, bf16, s);
     }
     // ---- compositing
     hipLaunchKernelGGL(train_composite_bwd_kernel, dim3((unsigned)((Rr + 3) / 4)), dim3(256), 0, s, *g, saved + sv.xr, saved + sv.g,
@@ -571,24 +610,22 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
     // ---- RGB_layer_1
     {
         Gemm32 q = mk(P, 384, 192, dG, 192, 0, p->weight[10], 384 + A, 1, dxr, XR_LD);  // dX = dG Wr1[:, 0:384]
-        n3dt_gemm32(q, s);
+        n3dt_gemm(q, bf16, s);
         Gemm32 w = mk(192, 384, P, dG, 192, 1, saved + sv.xr, XR_LD, 1, gp->weight[10], 384 + A);  // dWr1[:, 0:384] += dG^T X
         set_grad_split(w, P);
-        n3dt_gemm32(w, s);
-        hipLaunchKernelGGL(train_colsum_kernel, dim3(1, 64, B), dim3(256), 0, s, dG, 192L, ppf, 192, dfold + n3dt_bias_offset(10),
-                           (long)N3DT_FOLD_STRIDE);
+        n3dt_gemm(w, bf16, s);
+        launch_colsum(dG, 192L, ppf, B, 192, dfold + n3dt_bias_offset(10), (long)N3DT_FOLD_STRIDE, s);
     }
     // ---- RGB_layer_0 | density: dH7 = dXR Wc, gated by relu(H7)
     {
         Gemm32 q = mk(P, 384, 385, dxr, XR_LD, 0, ws + wl.wc, 384, 1, dha, 384);
         q.gate = hptr(7); q.ldgate = hld(7); q.gate_act = G32_ACT_RELU;
-        n3dt_gemm32(q, s);
+        n3dt_gemm(q, bf16, s);
         Gemm32 w = mk(385, 384, P, dxr, XR_LD, 1, hptr(7), hld(7), 1, ws + wl.dwc, 384);
         set_grad_split(w, P);
-        n3dt_gemm32(w, s);
+        n3dt_gemm(w, bf16, s);
         // bias grads of RGB_layer_0 (cols 0..383) and density (col 384): one frame group of all rows
-        hipLaunchKernelGGL(train_colsum_kernel, dim3(2, 128, 1), dim3(256), 0, s, dxr, (long)XR_LD, P, 384, gp->bias[9], 0L);
-        hipLaunchKernelGGL(train_colsum_kernel, dim3(1, 128, 1), dim3(256), 0, s, dxr + 384, (long)XR_LD, P, 1, gp->bias[8], 0L);
+        launch_colsum(dxr, (long)XR_LD, P, 1, 385, ws + wl.bc, 0L, s);  // [d br0 (384) | d bd] into the packed scratch, copied out below
     }
     // ---- trunk, layers 7..0.  `dcur` = dL/dH_l (already gated by relu'(H_l))
     float* dcur = dha;
@@ -598,31 +635,30 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
         if (l == 5) {
             Gemm32 w = mk(384, 448, P, dcur, 384, 1, cat5, 448, 1, ws + wl.dw5p, 448);
             set_grad_split(w, P);
-            n3dt_gemm32(w, s);
+            n3dt_gemm(w, bf16, s);
         } else if (l == 0) {
             Gemm32 w = mk(384, 63, P, dcur, 384, 1, cat5, 448, 1, gp->weight[0], 63 + S + U);
             set_grad_split(w, P);
-            n3dt_gemm32(w, s);
+            n3dt_gemm(w, bf16, s);
         } else {
             Gemm32 w = mk(384, 384, P, dcur, 384, 1, hptr(l - 1), hld(l - 1), 1, gp->weight[l], 384);
             set_grad_split(w, P);
-            n3dt_gemm32(w, s);
+            n3dt_gemm(w, bf16, s);
         }
         if (l == 0 || l == 5) {
-            hipLaunchKernelGGL(train_colsum_kernel, dim3(2, 64, B), dim3(256), 0, s, dcur, 384L, ppf, 384, dfold + n3dt_bias_offset(l),
-                               (long)N3DT_FOLD_STRIDE);
+            launch_colsum(dcur, 384L, ppf, B, 384, dfold + n3dt_bias_offset(l), (long)N3DT_FOLD_STRIDE, s);
         } else {
-            hipLaunchKernelGGL(train_colsum_kernel, dim3(2, 128, 1), dim3(256), 0, s, dcur, 384L, P, 384, gp->bias[l], 0L);
+            launch_colsum(dcur, 384L, P, 1, 384, gp->bias[l], 0L, s);
         }
         const bool want_cam = d_R || d_T;
         if (want_cam && l == 5) {  // d PE from the skip layer: dH5 W5'[:, 0:64]
             Gemm32 q = mk(P, 64, 384, dcur, 384, 0, ws + wl.w5p, 448, 1, ws + wl.dpe, 64);
-            n3dt_gemm32(q, s);
+            n3dt_gemm(q, bf16, s);
         }
         if (want_cam && l == 0) {  // += dH0 W0[:, 0:63]
             Gemm32 q = mk(P, 63, 384, dcur, 384, 0, p->weight[0], 63 + S + U, 1, ws + wl.dpe, 64);
             q.accumulate = 1;
-            n3dt_gemm32(q, s);
+            n3dt_gemm(q, bf16, s);
             if (d_R) (void)hipMemsetAsync(d_R, 0, sizeof(float) * 9 * B, s);
             if (d_T) (void)hipMemsetAsync(d_T, 0, sizeof(float) * 3 * B, s);
             hipLaunchKernelGGL(train_camera_bwd_kernel, dim3((unsigned)((Rr + 3) / 4)), dim3(256), 0, s, *g, xy, Rm, Tv, Kinv, t_rand, cat5,
@@ -633,10 +669,11 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
         Gemm32 q = l == 5 ? mk(P, 384, 384, dcur, 384, 0, ws + wl.w5p + 64, 448, 1, dnext, 384)
                           : mk(P, 384, 384, dcur, 384, 0, p->weight[l], 384, 1, dnext, 384);
         q.gate = hptr(l - 1); q.ldgate = hld(l - 1); q.gate_act = G32_ACT_RELU;
-        n3dt_gemm32(q, s);
+        n3dt_gemm(q, bf16, s);
         float* t = dcur; dcur = dnext; dnext = t;
     }
-    hipLaunchKernelGGL(train_unpack_grads_kernel, dim3((384 * 448 + 255) / 256), dim3(256), 0, s, *gp, S, ws + wl.dw5p, ws + wl.dwc);
+    hipLaunchKernelGGL(train_unpack_grads_kernel, dim3((384 * 448 + 255) / 256), dim3(256), 0, s, *gp, S, ws + wl.dw5p, ws + wl.dwc,
+                       ws + wl.bc);
     hipLaunchKernelGGL(train_fold_bwd_kernel, dim3(3, B), dim3(256), 0, s, *p, *gp, S, A, U, B, shape, appea, audio, dfold, d_shape,
                        d_appea, d_audio);
 }

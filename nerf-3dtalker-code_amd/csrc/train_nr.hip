@@ -293,15 +293,31 @@ __global__ void nrt_add_kernel(size_t n, const float* __restrict__ a, float* __r
     if (i < n) x[i] += a[i];
 }
 
-// out[n] += sum_m X[m][n]
+// out[n] += sum_m X[m][n]: one thread = 4 adjacent columns x a 256-row chunk, 8 independent float4 loads in flight
 __global__ void nrt_colsum_kernel(const float* __restrict__ X, long ldx, long rows, int N, float* __restrict__ out) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const long per = (rows + gridDim.y - 1) / gridDim.y;
-    const long r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
-    float acc = 0.0f;
-    for (long r = r0; r < r1; ++r) acc += X[r * ldx + n];
-    atomicAdd(&out[n], acc);
+    const int t = threadIdx.x;
+    if (4 * t >= N) return;  // every N here is a multiple of 32
+    const long r0 = (long)blockIdx.x * 256, r1 = min(rows, r0 + 256);
+    const float* base = X + 4 * t;
+    f32x4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    long r = r0;
+    for (; r + 8 <= r1; r += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (r + u) * ldx);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u & 3] += v[u];
+    }
+    for (; r < r1; ++r) acc[0] += *reinterpret_cast<const f32x4*>(base + r * ldx);
+    const f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(&out[4 * t + j], s[j]);
+}
+static void launch_nrt_colsum(const float* X, long ldx, long rows, int N, float* out, hipStream_t s) {
+    const int threads = ((N / 4 + 63) / 64) * 64;
+    hipLaunchKernelGGL(nrt_colsum_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(threads), 0, s, X, ldx, rows, N, out);
 }
 
 // db[c] += sum over images and pixels of planar d_rgb
@@ -349,7 +365,7 @@ static int split_for(long K) {
 
 // featmap [nb][fs*fs][C] -> img [nb,3,P,P]; all intermediates kept in `saved`
 extern "C" void n3dt_launch_nr_train_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap, float* img,
-                                         float* saved, float* ws, hipStream_t s) {
+                                         float* saved, float* ws, int bf16, hipStream_t s) {
     const NrSaved sv = nr_saved_layout(g, nb);
     const NrWs wl = nr_ws_layout(g, nb);
     const int C = g->feat_nc, nblk = g->n_blocks;
@@ -365,16 +381,16 @@ extern "C" void n3dt_launch_nr_train_fwd(const N3dtGeom* g, int nb, const N3dtRe
         const int ci = nr_ch(C, i), co = nr_ch(C, i + 1), M = nb * h * h;
         Gemm32 q1 = mk(M, 2 * ci, ci, x, ci, 0, p->psu1_w[i], ci, 0, saved + sv.t1[i], 2 * ci);
         q1.bias = p->psu1_b[i]; q1.act = G32_ACT_LRELU;
-        n3dt_gemm32(q1, s);
+        n3dt_gemm(q1, bf16, s);
         Gemm32 q2 = mk(M, 4 * ci, 2 * ci, saved + sv.t1[i], 2 * ci, 0, p->psu2_w[i], 2 * ci, 0, saved + sv.tv[i], 4 * ci);
         q2.bias = p->psu2_b[i]; q2.act = G32_ACT_LRELU;
-        n3dt_gemm32(q2, s);
+        n3dt_gemm(q2, bf16, s);
         hipLaunchKernelGGL(nrt_shuffle_kernel, GRID1((size_t)M * 4 * ci), 0, s, nb, h, h, ci, saved + sv.tv[i], x, ps);
         h *= 2;
         hipLaunchKernelGGL(nrt_blur_kernel, GRID1((size_t)nb * h * h * (ci / 4)), 0, s, nb, h, h, ci, ps, saved + sv.bl[i]);
         Gemm32 q3 = mk(nb * h * h, co, ci, saved + sv.bl[i], ci, 0, p->feat_w[i], ci, 0, saved + sv.net[i], co);
         q3.bias = p->feat_b[i]; q3.act = G32_ACT_LRELU;
-        n3dt_gemm32(q3, s);
+        n3dt_gemm(q3, bf16, s);
         const bool last = i == nblk - 1;
         hipLaunchKernelGGL(nrt_to_rgb_kernel, GRID1((size_t)nb * h * h), 3 * co * sizeof(float), s, nb, h * h, co, saved + sv.net[i],
                            p->to_rgb_w[i + 1], p->to_rgb_b[i + 1], (const float*)rgbA, last ? saved + sv.img : rgbB, last ? 1 : 0);
@@ -388,7 +404,7 @@ extern "C" void n3dt_launch_nr_train_fwd(const N3dtGeom* g, int nb, const N3dtRe
 // gradients are ACCUMULATED into gp (same pointer layout as the parameters); d_featmap is overwritten
 extern "C" void n3dt_launch_nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N3dtRenderGrads* gp,
                                    const float* featmap, const float* d_img, const float* saved, float* d_featmap, float* ws,
-                                   hipStream_t s) {
+                                   int bf16, hipStream_t s) {
     const NrSaved sv = nr_saved_layout(g, nb);
     const NrWs wl = nr_ws_layout(g, nb);
     const int C = g->feat_nc, nblk = g->n_blocks;
@@ -410,7 +426,7 @@ extern "C" void n3dt_launch_nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderPa
         for (int im = 0; im < nb; ++im) {
             Gemm32 w = mk(3, co, HW, drgb + (size_t)im * 3 * HW, HW, 0, net + (size_t)im * HW * co, co, 1, gp->to_rgb_w[i + 1], co);
             set_grad_split(w, HW);
-            n3dt_gemm32(w, s);
+            n3dt_gemm(w, bf16, s);
         }
         hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[i + 1]);
         // d net: from the rgb branch (+ from the next stage's input gradient, already in dnet when i < nblk-1)
@@ -427,10 +443,10 @@ extern "C" void n3dt_launch_nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderPa
         {
             Gemm32 w = mk(co, ci, M4, dnet, co, 1, saved + sv.bl[i], ci, 1, gp->feat_w[i], ci);
             set_grad_split(w, M4);
-            n3dt_gemm32(w, s);
-            hipLaunchKernelGGL(nrt_colsum_kernel, dim3((co + 255) / 256, 256), dim3(256), 0, s, dnet, (long)co, (long)M4, co, gp->feat_b[i]);
+            n3dt_gemm(w, bf16, s);
+            launch_nrt_colsum(dnet, (long)co, (long)M4, co, gp->feat_b[i], s);
             Gemm32 q = mk(M4, ci, co, dnet, co, 0, p->feat_w[i], ci, 1, bufB, ci);  // d bl
-            n3dt_gemm32(q, s);
+            n3dt_gemm(q, bf16, s);
         }
         // blur adjoint -> d ps (bufC), then un-shuffle into d tv (bufB, gated) and the residual gradient (bufA)
         hipLaunchKernelGGL(nrt_blur_adj_kernel, GRID1((size_t)M4 * (ci / 4)), 0, s, nb, h, h, ci, bufB, bufC);
@@ -441,23 +457,21 @@ extern "C" void n3dt_launch_nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderPa
         {
             Gemm32 w = mk(4 * ci, 2 * ci, M, dtv, 4 * ci, 1, saved + sv.t1[i], 2 * ci, 1, gp->psu2_w[i], 2 * ci);
             set_grad_split(w, M);
-            n3dt_gemm32(w, s);
-            hipLaunchKernelGGL(nrt_colsum_kernel, dim3((4 * ci + 255) / 256, 128), dim3(256), 0, s, dtv, (long)4 * ci, (long)M, 4 * ci,
-                               gp->psu2_b[i]);
+            n3dt_gemm(w, bf16, s);
+            launch_nrt_colsum(dtv, (long)4 * ci, (long)M, 4 * ci, gp->psu2_b[i], s);
             Gemm32 q = mk(M, 2 * ci, 4 * ci, dtv, 4 * ci, 0, p->psu2_w[i], 2 * ci, 1, bufC, 2 * ci);  // d t1, gated by lrelu'(t1)
             q.gate = saved + sv.t1[i]; q.ldgate = 2 * ci; q.gate_act = G32_ACT_LRELU;
-            n3dt_gemm32(q, s);
+            n3dt_gemm(q, bf16, s);
         }
         // layer_1: t1 = lrelu(x W1^T + b1);  dx = dt1 W1 + residual gradient
         {
             Gemm32 w = mk(2 * ci, ci, M, bufC, 2 * ci, 1, x, ci, 1, gp->psu1_w[i], ci);
             set_grad_split(w, M);
-            n3dt_gemm32(w, s);
-            hipLaunchKernelGGL(nrt_colsum_kernel, dim3((2 * ci + 255) / 256, 128), dim3(256), 0, s, bufC, (long)2 * ci, (long)M, 2 * ci,
-                               gp->psu1_b[i]);
+            n3dt_gemm(w, bf16, s);
+            launch_nrt_colsum(bufC, (long)2 * ci, (long)M, 2 * ci, gp->psu1_b[i], s);
             Gemm32 q = mk(M, ci, 2 * ci, bufC, 2 * ci, 0, p->psu1_w[i], ci, 1, dxres, ci);
             q.accumulate = 1;
-            n3dt_gemm32(q, s);
+            n3dt_gemm(q, bf16, s);
         }
         // rgb pyramid: at stage i > 0 the running rgb came from rgb_upsample of the previous sum
         h = hin;
@@ -475,7 +489,7 @@ extern "C" void n3dt_launch_nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderPa
         for (int im = 0; im < nb; ++im) {
             Gemm32 w = mk(3, C, HW, drgb + (size_t)im * 3 * HW, HW, 0, featmap + (size_t)im * HW * C, C, 1, gp->to_rgb_w[0], C);
             set_grad_split(w, HW);
-            n3dt_gemm32(w, s);
+            n3dt_gemm(w, bf16, s);
         }
         hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[0]);
         hipLaunchKernelGGL(nrt_to_rgb_bwd_kernel, GRID1((size_t)nb * HW * (C / 4)), 3 * C * sizeof(float), s, nb, HW, C, drgb,

@@ -88,17 +88,17 @@ def lib():
     L.n3dt_render_train_workspace_bytes.restype = sz
     L.n3dt_render_train_workspace_bytes.argtypes = [gp]
     L.n3dt_render_train_fwd.restype = ci
-    L.n3dt_render_train_fwd.argtypes = [gp, vp, mp] + [vp] * 13 + [vp, sz, vp, sz, vp]
+    L.n3dt_render_train_fwd.argtypes = [gp, ci, vp, mp] + [vp] * 13 + [vp, sz, vp, sz, vp]
     L.n3dt_render_bwd.restype = ci
-    L.n3dt_render_bwd.argtypes = [gp, mp, mp] + [vp] * 7 + [vp, sz] + [vp] * 11 + [vp, sz, vp]
+    L.n3dt_render_bwd.argtypes = [gp, ci, mp, mp] + [vp] * 7 + [vp, sz] + [vp] * 11 + [vp, sz, vp]
     L.n3dt_neural_render_train_saved_bytes.restype = sz
     L.n3dt_neural_render_train_saved_bytes.argtypes = [gp, ci]
     L.n3dt_neural_render_train_workspace_bytes.restype = sz
     L.n3dt_neural_render_train_workspace_bytes.argtypes = [gp, ci]
     L.n3dt_neural_render_train_fwd.restype = ci
-    L.n3dt_neural_render_train_fwd.argtypes = [gp, ci, rp, vp, vp, vp, sz, vp, sz, vp]
+    L.n3dt_neural_render_train_fwd.argtypes = [gp, ci, ci, rp, vp, vp, vp, sz, vp, sz, vp]
     L.n3dt_neural_render_bwd.restype = ci
-    L.n3dt_neural_render_bwd.argtypes = [gp, ci, rp, rp, vp, vp, vp, sz, vp, vp, sz, vp]
+    L.n3dt_neural_render_bwd.argtypes = [gp, ci, ci, rp, rp, vp, vp, vp, sz, vp, vp, sz, vp]
     L.n3dt_loss_fwd.restype = ci
     L.n3dt_loss_fwd.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp]
     L.n3dt_loss_bwd.restype = ci

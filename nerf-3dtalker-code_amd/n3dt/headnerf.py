@@ -97,6 +97,7 @@ class NeuralRenderer(nn.Module):
         super().__init__()
         assert out_dim == 3 and final_actvn and min_feat == 32
         self.bg_type = bg_type
+        self.train_precision = "fp32"  # "bf16": matrix products of the differentiable path on bf16 MFMA
         self.featmap_size = featmap_size
         self.n_feat = feat_nc
         self.out_dim = out_dim
@@ -181,7 +182,8 @@ class _RenderFn(torch.autograd.Function):
         shape_c, appea_c = ops._f32c(shape), ops._f32c(appea)
         audio_c = ops._f32c(audio) if geom.audio_dim > 0 else None
         bg = bg_featmap.detach().reshape(geom.feat_nc, -1).contiguous()
-        out, saved = ops.render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape_c, appea_c, audio_c, t_rand, bg)
+        ctx.prec = _lib.PRECISIONS[net.train_precision]
+        out, saved = ops.render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape_c, appea_c, audio_c, t_rand, bg, ctx.prec)
         ctx.geom, ctx.saved, ctx.keep = geom, saved, (ws, bs, shape_c, appea_c, audio_c, bg)
         ctx.cam = (xy, R, T, Kinv, t_rand) if ctx.want_cam else None
         ctx.bg_shape = bg_featmap.shape
@@ -195,7 +197,7 @@ class _RenderFn(torch.autograd.Function):
         gws = [torch.zeros_like(w) for w in ws]
         gbs = [torch.zeros_like(b) for b in bs]
         d_bg, d_shape, d_appea, d_audio, d_R, d_T = ops.render_bwd(geom, ops.mlp_params(ws, bs), ops.mlp_params(gws, gbs), shape_c,
-                                                                   appea_c, audio_c, bg, d_merge.contiguous(), ctx.saved, ctx.cam)
+                                                                   appea_c, audio_c, bg, d_merge.contiguous(), ctx.saved, ctx.cam, ctx.prec)
         ctx.saved = None
         grads = [g.view(s) for g, s in zip(gws + gbs, ctx.mlp_shapes)]
         if d_T is not None:
@@ -213,7 +215,8 @@ class _NeuralRenderFn(torch.autograd.Function):
         tensors = [t.detach().view(t.shape[0], -1).contiguous() if t.dim() == 4 else t.detach().contiguous() for t in flat]
         rp = nr._rparams_from(tensors)
         fm = featmap.detach().contiguous()
-        img, saved = ops.neural_render_train_fwd(geom, nb, rp, fm)
+        ctx.prec = _lib.PRECISIONS[nr.train_precision]
+        img, saved = ops.neural_render_train_fwd(geom, nb, rp, fm, ctx.prec)
         ctx.nr, ctx.geom, ctx.nb, ctx.saved, ctx.keep = nr, geom, nb, saved, (tensors, fm)
         ctx.shapes = [t.shape for t in flat]
         return img
@@ -223,7 +226,7 @@ class _NeuralRenderFn(torch.autograd.Function):
         tensors, fm = ctx.keep
         gt = [torch.zeros_like(t) for t in tensors]
         d_feat = ops.neural_render_bwd(ctx.geom, ctx.nb, ctx.nr._rparams_from(tensors), ctx.nr._rparams_from(gt), fm,
-                                       d_img.contiguous(), ctx.saved)
+                                       d_img.contiguous(), ctx.saved, ctx.prec)
         ctx.saved = None
         return (None, d_feat, *[g.view(s) for g, s in zip(gt, ctx.shapes)])
 
@@ -240,7 +243,8 @@ class _Seam(nn.Module):
 
 
 class HeadNeRFNet(nn.Module):
-    def __init__(self, opt, include_vd, hier_sampling, include_gaze=False, eye_gaze_dim=2, audio_dim=64, precision="fp32"):
+    def __init__(self, opt, include_vd, hier_sampling, include_gaze=False, eye_gaze_dim=2, audio_dim=64, precision="fp32",
+                 train_precision="fp32"):
         super().__init__()
         if hier_sampling:
             # the reference's fine branch raises TypeError at its call site (HeadNeRFNet.py:182-185)
@@ -252,9 +256,12 @@ class HeadNeRFNet(nn.Module):
         self.include_gaze = include_gaze
         self.eye_gaze_dim = eye_gaze_dim
         self.audio_dim = audio_dim
-        self.precision = precision
+        self.precision = precision              # inference path: "fp32" (parity) | "bf16" | "fp16"
+        assert train_precision in ("fp32", "bf16")
+        self.train_precision = train_precision  # differentiable path: "fp32" (exact) | "bf16" (bf16-MFMA products)
         self._build_info(opt)
         self._build_tool_funcs()
+        self.neural_render.train_precision = train_precision
         self._pack_cache = {}
 
     def _build_info(self, opt):

@@ -147,7 +147,7 @@ def _bytes_or_raise(n, what):
     return n
 
 
-def render_train_fwd(geom, packed_f32, params, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap):
+def render_train_fwd(geom, packed_f32, params, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap, precision=0):
     """Forward with saved activations.  Returns (out dict, saved buffer)."""
     dev = xy.device
     B, Nr, C = geom.batch, geom.n_rays, geom.feat_nc
@@ -161,13 +161,13 @@ def render_train_fwd(geom, packed_f32, params, xy, R, T, Kinv, shape, appea, aud
     saved = torch.empty(sbytes, dtype=torch.uint8, device=dev)
     ws = WORKSPACE.get("train", wbytes, dev)
     check(lib().n3dt_render_train_fwd(
-        ctypes.byref(geom), _ptr(packed_f32), ctypes.byref(params), _ptr(xy), _ptr(R), _ptr(T), _ptr(Kinv), _ptr(shape), _ptr(appea),
+        ctypes.byref(geom), precision, _ptr(packed_f32), ctypes.byref(params), _ptr(xy), _ptr(R), _ptr(T), _ptr(Kinv), _ptr(shape), _ptr(appea),
         _ptr(audio), _ptr(t_rand), _ptr(bg_featmap), _ptr(out["fg_feat"]), _ptr(out["bg_alpha"]), None, _ptr(out["merge_feat"]),
         _ptr(saved), sbytes, _ptr(ws), wbytes, _stream()), "n3dt_render_train_fwd")
     return out, saved
 
 
-def render_bwd(geom, params, grads, shape, appea, audio, bg_featmap, d_merge, saved, cam=None):
+def render_bwd(geom, params, grads, shape, appea, audio, bg_featmap, d_merge, saved, cam=None, precision=0):
     """Backward of render_train_fwd.  `grads` (MlpParams struct of zeroed tensors) is accumulated into.
     cam = (xy, R, T, Kinv, t_rand) requests camera gradients.
     Returns (d_bg_featmap [C,Nr], d_shape, d_appea, d_audio, d_R, d_T)."""
@@ -186,13 +186,13 @@ def render_bwd(geom, params, grads, shape, appea, audio, bg_featmap, d_merge, sa
     wbytes = lib().n3dt_render_train_workspace_bytes(ctypes.byref(geom))
     ws = WORKSPACE.get("train", wbytes, dev)
     check(lib().n3dt_render_bwd(
-        ctypes.byref(geom), ctypes.byref(params), ctypes.byref(grads), _ptr(shape), _ptr(appea), _ptr(audio), _ptr(bg_featmap),
+        ctypes.byref(geom), precision, ctypes.byref(params), ctypes.byref(grads), _ptr(shape), _ptr(appea), _ptr(audio), _ptr(bg_featmap),
         _ptr(d_merge), None, None, _ptr(saved), saved.numel(), _ptr(d_bg), _ptr(d_shape), _ptr(d_appea), _ptr(d_audio),
         *cam_ptrs, _ptr(d_R), _ptr(d_T), _ptr(ws), wbytes, _stream()), "n3dt_render_bwd")
     return d_bg, d_shape, d_appea, d_audio, d_R, d_T
 
 
-def neural_render_train_fwd(geom, nb, rparams, featmap):
+def neural_render_train_fwd(geom, nb, rparams, featmap, precision=0):
     dev = featmap.device
     P = geom.featmap_size << geom.n_blocks
     img = torch.empty(nb, 3, P, P, dtype=torch.float32, device=dev)
@@ -201,16 +201,16 @@ def neural_render_train_fwd(geom, nb, rparams, featmap):
                              "n3dt_neural_render_train_workspace_bytes")
     saved = torch.empty(sbytes, dtype=torch.uint8, device=dev)
     ws = WORKSPACE.get("nr_train", wbytes, dev)
-    check(lib().n3dt_neural_render_train_fwd(ctypes.byref(geom), nb, ctypes.byref(rparams), _ptr(featmap), _ptr(img), _ptr(saved), sbytes,
+    check(lib().n3dt_neural_render_train_fwd(ctypes.byref(geom), nb, precision, ctypes.byref(rparams), _ptr(featmap), _ptr(img), _ptr(saved), sbytes,
                                              _ptr(ws), wbytes, _stream()), "n3dt_neural_render_train_fwd")
     return img, saved
 
 
-def neural_render_bwd(geom, nb, rparams, rgrads, featmap, d_img, saved):
+def neural_render_bwd(geom, nb, rparams, rgrads, featmap, d_img, saved, precision=0):
     dev = featmap.device
     d_feat = torch.empty_like(featmap)
     wbytes = lib().n3dt_neural_render_train_workspace_bytes(ctypes.byref(geom), nb)
     ws = WORKSPACE.get("nr_train", wbytes, dev)
-    check(lib().n3dt_neural_render_bwd(ctypes.byref(geom), nb, ctypes.byref(rparams), ctypes.byref(rgrads), _ptr(featmap), _ptr(d_img),
+    check(lib().n3dt_neural_render_bwd(ctypes.byref(geom), nb, precision, ctypes.byref(rparams), ctypes.byref(rgrads), _ptr(featmap), _ptr(d_img),
                                        _ptr(saved), saved.numel(), _ptr(d_feat), _ptr(ws), wbytes, _stream()), "n3dt_neural_render_bwd")
     return d_feat
