@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32 g) {
     __shared__ float Bs[G_BK][G_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * G_BM, n0 = blockIdx.y * G_BN;
+    // blockIdx.x walks the N tiles: the few column tiles that share one 128-row slab of A are dispatched back to
+    // back, so the slab is fetched from HBM once and re-read from the Infinity Cache (A is the big operand here)
+    const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;
     int kbeg = 0, kend = g.K;
     if (g.split_k > 1) {
         const int per = ((g.K + g.split_k - 1) / g.split_k + G_BK - 1) / G_BK * G_BK;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32 g) {
 
 void n3dt_gemm32(const Gemm32& g, hipStream_t stream) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
-    dim3 grid((g.M + G_BM - 1) / G_BM, (g.N + G_BN - 1) / G_BN, g.split_k > 1 ? g.split_k : 1);
+    dim3 grid((g.N + G_BN - 1) / G_BN, (g.M + G_BM - 1) / G_BM, g.split_k > 1 ? g.split_k : 1);
     hipLaunchKernelGGL(gemm32_kernel, grid, dim3(256), 0, stream, g);
 }
 
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm32 g) {
     __shared__ __attribute__((aligned(16))) unsigned short Bs[G_BN * H_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * G_BM, n0 = blockIdx.y * G_BN;
+    const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;  // N tiles fastest, see gemm32_kernel
     int kbeg = 0, kend = g.K;
     if (g.split_k > 1) {
         const int per = ((g.K + g.split_k - 1) / g.split_k + H_BK - 1) / H_BK * H_BK;
@@ -269,6 +271,6 @@ void n3dt_gemm(const Gemm32& g, int bf16, hipStream_t stream) {
         return;
     }
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
-    dim3 grid((g.M + G_BM - 1) / G_BM, (g.N + G_BN - 1) / G_BN, g.split_k > 1 ? g.split_k : 1);
+    dim3 grid((g.N + G_BN - 1) / G_BN, (g.M + G_BM - 1) / G_BM, g.split_k > 1 ? g.split_k : 1);
     hipLaunchKernelGGL(gemm16_kernel, grid, dim3(256), 0, stream, g);
 }
