@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.join(REPO, "nerf-3dtalker-code_amd"))
 sys.path.insert(0, REPO)
 
 FLOP_PER_POINT = 2702592          # latent-folded MLP query, SURVEY 8(d)
-FLOP_PER_POINT_EXECUTED = 2 * 1314816  # MFMA work actually issued per point (padded tiles; RGB_layer_2 runs per ray)
+FLOP_PER_POINT_EXECUTED = 2675 * 32768 // 32  # MFMA work actually issued per point: 2568 weight pieces + 107 bias MFMAs per 32 samples
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
 
 
