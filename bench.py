@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.join(REPO, "nerf-3dtalker-code_amd"))
 sys.path.insert(0, REPO)
 
 FLOP_PER_POINT = 2702592          # latent-folded MLP query, SURVEY 8(d)
-FLOP_PER_POINT_EXECUTED = 2675 * 32768 // 32  # MFMA work actually issued per point: 2568 weight pieces + 107 bias MFMAs per 32 samples
+FLOP_PER_POINT_EXECUTED = 2375 * 32768 // 32  # MFMA work actually issued per point: 2280 weight pieces + 95 bias MFMAs per 32 samples (RGB_layer_0 merged into RGB_layer_1, RGB_layer_2 per ray)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
 
 

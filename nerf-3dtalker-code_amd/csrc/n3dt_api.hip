@@ -10,7 +10,7 @@
 
 extern "C" {
 void n3dt_launch_pack(const N3dtGeom*, int, const N3dtMlpParams*, void*, hipStream_t);
-void n3dt_launch_fold(const N3dtGeom*, const N3dtMlpParams*, const float*, const float*, const float*, float*, hipStream_t);
+void n3dt_launch_fold(const N3dtGeom*, const N3dtMlpParams*, const float*, const float*, const float*, float*, int, hipStream_t);
 void n3dt_launch_ray_head(const N3dtGeom*, int, int, const float*, const float*, const float*, const float*, float*, float*,
                           float*, float*, float*, hipStream_t);
 void n3dt_launch_chw_to_hwc(int, int, const float*, float*, hipStream_t);
@@ -157,7 +157,7 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
     float* fold = (float*)(ws + c.fold);
     float* part = (float*)(ws + c.part);
     float* wlocal = (float*)(ws + c.wlocal);
-    n3dt_launch_fold(g, p, shape, appea, audio, fold, s);
+    n3dt_launch_fold(g, p, shape, appea, audio, fold, precision != N3DT_F32, s);
     const bool prof = g_prof_cap > 0 && g_prof_n < g_prof_cap;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_n], s);
     if (precision == N3DT_F32)

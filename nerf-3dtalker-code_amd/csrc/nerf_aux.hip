@@ -30,9 +30,16 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
     return __builtin_bit_cast(unsigned short, h);
 }
 
+// 16-bit precisions stream ONE merged matrix for RGB_layer_0 -> RGB_layer_1: there is no activation between the
+// two layers (models.py:79-81), so W_m = Wr1[:, 0:384] . Wr0 (192 x 384) replaces 12 + 6 out tiles by 6.  It is
+// stored at stage 9's offset (right behind the density stage, keeping the stream contiguous); stage 10's slot stays
+// unused.  The exact-fp32 kernel keeps the two layers separate (the reference's operation order).
 __global__ void pack_mlp_kernel(N3dtMlpParams p, int precision, int S, int A, int U, unsigned char* __restrict__ out) {
     const int stage = blockIdx.y;
-    const N3dtStage st = n3dt_stage(stage);
+    const bool merged = precision != N3DT_F32 && stage == 9;
+    if (precision != N3DT_F32 && stage == 10) return;
+    N3dtStage st = n3dt_stage(stage);
+    if (merged) st = n3dt_stage(10);  // 192 x 384
     const size_t n = (size_t)st.N * st.K;
     const size_t base = n3dt_stage_offset(stage);
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
@@ -50,7 +57,14 @@ __global__ void pack_mlp_kernel(N3dtMlpParams p, int precision, int S, int A, in
             row = ot * 32 + (lane & 31);
             col = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
         }
-        float v = logical_weight(p, stage, row, col, S, A, U);
+        float v;
+        if (merged) {
+            const float* w1 = p.weight[10] + (size_t)row * (N3DT_HID + A);
+            v = 0.0f;
+            for (int j = 0; j < N3DT_HID; ++j) v = fmaf(w1[j], p.weight[9][(size_t)j * N3DT_HID + col], v);
+        } else {
+            v = logical_weight(p, stage, row, col, S, A, U);
+        }
         if (precision == N3DT_F32) {
             reinterpret_cast<float*>(out)[base + e] = v;
         } else if (precision == N3DT_BF16) {
@@ -90,7 +104,7 @@ extern "C" void n3dt_launch_pack(const N3dtGeom* g, int precision, const N3dtMlp
 //   br1'[o] = br1[o] + Wr1[o, 384:].appea
 // grid (B, N3DT_NSTAGE), block 384
 // ---------------------------------------------------------------------------------------------
-__global__ void fold_latents_kernel(N3dtMlpParams p, int S, int A, int U, const float* __restrict__ shape,
+__global__ void fold_latents_kernel(N3dtMlpParams p, int S, int A, int U, int merged, const float* __restrict__ shape,
                                     const float* __restrict__ appea, const float* __restrict__ audio, float* __restrict__ fold) {
     const int b = blockIdx.x, stage = blockIdx.y, o = threadIdx.x;
     __shared__ float code[512];
@@ -116,13 +130,17 @@ __global__ void fold_latents_kernel(N3dtMlpParams p, int S, int A, int U, const 
     else if (stage == 5) w = p.weight[5] + (size_t)o * in5 + N3DT_PE_DIM;
     else if (stage == 10) w = p.weight[10] + (size_t)o * inr + N3DT_HID;
     for (int i = 0; i < n_code; ++i) acc = fmaf(w[i], code[i], acc);
+    if (stage == 10 && merged) {  // bias of the merged RGB_layer_0 -> RGB_layer_1 matrix: br1' + Wr1[:, 0:384] . br0
+        const float* w1 = p.weight[10] + (size_t)o * inr;
+        for (int j = 0; j < N3DT_HID; ++j) acc = fmaf(w1[j], p.bias[9][j], acc);
+    }
     out[o] = acc;
 }
 
 extern "C" void n3dt_launch_fold(const N3dtGeom* g, const N3dtMlpParams* p, const float* shape, const float* appea,
-                                 const float* audio, float* fold, hipStream_t stream) {
+                                 const float* audio, float* fold, int merged_rgb, hipStream_t stream) {
     hipLaunchKernelGGL(fold_latents_kernel, dim3(g->batch, N3DT_NSTAGE), dim3(384), 0, stream, *p, g->shape_dim, g->appea_dim,
-                       g->audio_dim, shape, appea, audio, fold);
+                       g->audio_dim, merged_rgb, shape, appea, audio, fold);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define X16_BS 32
 #define X16_CH 24                      // pieces per chunk (24 KiB)
 #define X16_PIECE 1024                 // bytes
-#define X16_NCHUNK (2568 / X16_CH)     // 48 + 7*288 + 336 + 24 + 144 pieces
+#define X16_NCHUNK (2280 / X16_CH)     // 48 + 6*288 + 336 + 24 + 144 pieces (RGB_layer_0 is merged into RGB_layer_1)
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
@@ -489,10 +489,9 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
 #endif
         aux[nb] = w;
     }
-    // RGB_layer_0 (linear, models.py:79)
-    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 12, MODE_LINEAR>(ws, fb + n3dt_bias_offset(9), pe, nullptr, hb, ha, aux, po, live, lane);
-    // RGB_layer_1 (+appearance fold, relu; models.py:80-81), weighted by the sample weights and reduced over the samples
-    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 6, MODE_COMPOSITE>(ws, fb + n3dt_bias_offset(10), pe, nullptr, ha, hb, aux, po, live, lane);
+    // RGB_layer_0 -> RGB_layer_1 as ONE merged 192 x 384 layer on h7 (no activation sits between them, models.py:79-81;
+    // merged matrix and bias built by pack / fold), relu, weighted by the sample weights and reduced over the samples
+    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 6, MODE_COMPOSITE>(ws, fb + n3dt_bias_offset(10), pe, nullptr, hb, ha, aux, po, live, lane);
 #ifdef X16_STAMP
     if (wlocal && lane == 0 && live[0]) {
         float* dbg = wlocal + (size_t)blk[0] * X16_BS;

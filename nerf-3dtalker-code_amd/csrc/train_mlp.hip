@@ -490,7 +490,7 @@ __global__ void train_unpack_grads_kernel(N3dtMlpGrads gp, int S, const float* _
 // ---------------------------------------------------------------------------------------------
 // orchestration
 // ---------------------------------------------------------------------------------------------
-extern "C" void n3dt_launch_fold(const N3dtGeom*, const N3dtMlpParams*, const float*, const float*, const float*, float*, hipStream_t);
+extern "C" void n3dt_launch_fold(const N3dtGeom*, const N3dtMlpParams*, const float*, const float*, const float*, float*, int, hipStream_t);
 extern "C" void n3dt_launch_ray_head(const N3dtGeom*, int, int, const float*, const float*, const float*, const float*, float*,
                                      float*, float*, float*, float*, hipStream_t);
 
@@ -531,7 +531,7 @@ extern "C" void n3dt_launch_train_fwd(const N3dtGeom* g, const N3dtMlpParams* p,
     const int S = g->shape_dim, A = g->appea_dim, U = g->audio_dim;
     float* fold = saved + sv.fold;
     float* cat5 = saved + sv.cat5;
-    n3dt_launch_fold(g, p, shape, appea, audio, fold, s);
+    n3dt_launch_fold(g, p, shape, appea, audio, fold, 0, s);
     hipLaunchKernelGGL(train_pack_kernel, dim3((385 * 384 + 384 * 448 + 255) / 256), dim3(256), 0, s, *p, S, ws + wl.w5p, ws + wl.wc,
                        ws + wl.bc);
     hipLaunchKernelGGL(train_sample_pe_kernel, dim3((unsigned)(((size_t)P * 4 + 255) / 256)), dim3(256), 0, s, *g, xy, R, T, Kinv, t_rand,
