@@ -17,6 +17,8 @@
 // Epilogue per 32-sample block: density -> alpha -> in-block transmittance scan over the 32
 // lanes -> weights; the RGB_layer_1 activations are weighted and reduced over the samples with a
 // 5-step butterfly, so the only HBM traffic per block is one 196-float partial.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "n3dt_device.h"
@@ -130,6 +132,9 @@ struct X16<N3DT_F16> {
 #endif
 #ifndef X16_DEFER
 #define X16_DEFER 0
+#endif
+#ifndef X16_DEFAULT_TILING
+#define X16_DEFAULT_TILING 1  // 1: 8 waves x 32 samples, 2: 4 waves x 64 samples (N3DT_X16_TILING overrides at run time)
 #endif
 #define X16_NBUF 3
 #define X16_CHUNK_BYTES (X16_CH * X16_PIECE)
@@ -534,6 +539,19 @@ static void launch_x16(const N3dtGeom* g, const void* packed, const float* fold,
 extern "C" void n3dt_launch_nerf_fwd_x16(const N3dtGeom* g, int precision, const void* packed, const float* fold, const float* xy,
                                          const float* R, const float* T, const float* Kinv, const float* t_rand, float* part,
                                          float* wlocal, hipStream_t stream) {
-    if (precision == N3DT_BF16) launch_x16<N3DT_BF16, 1, 8>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, stream);
-    else launch_x16<N3DT_F16, 1, 8>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, stream);
+    // two tilings of the same kernel: 8 waves x 32 samples (2 waves per SIMD, <= 256 registers) or 4 waves x 64 samples
+    // (one wave per SIMD with the whole 512-register file: each weight fragment read from LDS feeds two MFMAs)
+    static const int wide = [] {
+        const char* e = getenv("N3DT_X16_TILING");
+        return e ? atoi(e) : X16_DEFAULT_TILING;
+    }();
+    const long blocks = (long)g->batch * g->n_rays * ((g->n_samples + X16_BS - 1) / X16_BS);
+    const bool use_wide = wide == 2 && (((long)g->n_rays * ((g->n_samples + X16_BS - 1) / X16_BS)) % 2 == 0) && blocks >= 2;
+    if (precision == N3DT_BF16) {
+        if (use_wide) launch_x16<N3DT_BF16, 2, 4>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, stream);
+        else launch_x16<N3DT_BF16, 1, 8>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, stream);
+    } else {
+        if (use_wide) launch_x16<N3DT_F16, 2, 4>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, stream);
+        else launch_x16<N3DT_F16, 1, 8>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, stream);
+    }
 }
