@@ -27,6 +27,14 @@ void n3dt_launch_train_fwd(const N3dtGeom*, const N3dtMlpParams*, const float*, 
 void n3dt_launch_train_bwd(const N3dtGeom*, const N3dtMlpParams*, const N3dtMlpGrads*, const float*, const float*, const float*,
                            const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*,
                            const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, hipStream_t);
+size_t n3dt_train16_saved_bytes(const N3dtGeom*);
+size_t n3dt_train16_ws_bytes(const N3dtGeom*);
+void n3dt_launch_train16_fwd(const N3dtGeom*, const N3dtMlpParams*, const void*, const float*, const float*, const float*, const float*,
+                             const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*,
+                             float*, void*, void*, hipStream_t);
+void n3dt_launch_train16_bwd(const N3dtGeom*, const N3dtMlpParams*, const N3dtMlpGrads*, const float*, const float*, const float*,
+                             const float*, const float*, const float*, const float*, const void*, float*, float*, float*, float*, void*,
+                             hipStream_t);
 void n3dt_launch_loss_fwd(int, int, const float*, const float*, const float*, const float*, float, float*, float*, hipStream_t);
 void n3dt_launch_loss_bwd(int, int, const float*, const float*, const float*, const float*, float, const float*, const float*, float*,
                           float*, hipStream_t);
@@ -210,13 +218,15 @@ static int check_train_geom(const N3dtGeom* g) {
     return N3DT_OK;
 }
 
+// one size serves both training precisions (the fp32 layered path and the fused bf16 path lay the buffers out differently)
+static inline size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 extern "C" size_t n3dt_render_train_saved_bytes(const N3dtGeom* g) {
     if (check_train_geom(g) != N3DT_OK) return 0;
-    return n3dt_train_saved_floats(g) * sizeof(float);
+    return max_sz(n3dt_train_saved_floats(g) * sizeof(float), n3dt_train16_saved_bytes(g));
 }
 extern "C" size_t n3dt_render_train_workspace_bytes(const N3dtGeom* g) {
     if (check_train_geom(g) != N3DT_OK) return 0;
-    return n3dt_train_ws_floats(g) * sizeof(float);
+    return max_sz(n3dt_train_ws_floats(g) * sizeof(float), n3dt_train16_ws_bytes(g));
 }
 
 extern "C" int n3dt_render_train_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, const N3dtMlpParams* p, const float* xy, const float* R,
@@ -233,10 +243,16 @@ extern "C" int n3dt_render_train_fwd(const N3dtGeom* g, int precision, const voi
     if (merge_feat && !bg_featmap) return fail(N3DT_EINVAL, "n3dt_render_train_fwd: merge_feat needs bg_featmap");
     if (saved_bytes < n3dt_render_train_saved_bytes(g)) return fail(N3DT_EWORKSPACE, "n3dt_render_train_fwd: saved buffer too small");
     if (workspace_bytes < n3dt_render_train_workspace_bytes(g)) return fail(N3DT_EWORKSPACE, "n3dt_render_train_fwd: workspace too small");
-    // the fp32 tail (W2^T, b2) sits at the same place in a packed buffer of any precision given to us as F32-packed
-    const float* tail = (const float*)((const unsigned char*)packed_mlp + n3dt_packed_tail_offset(N3DT_F32));
+    // `packed_mlp` is the n3dt_mlp_pack buffer of the SAME precision: the fused bf16 path streams its bf16 matrices,
+    // the fp32 path only reads the fp32 tail (W2^T, b2) behind them
+    const float* tail = (const float*)((const unsigned char*)packed_mlp + n3dt_packed_tail_offset(precision));
+    if (precision == N3DT_BF16) {
+        n3dt_launch_train16_fwd(g, p, packed_mlp, tail, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap, fg_feat, bg_alpha, depth,
+                                merge_feat, saved, workspace, (hipStream_t)stream);
+        return check_hip("n3dt_render_train_fwd");
+    }
     n3dt_launch_train_fwd(g, p, tail, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap, fg_feat, bg_alpha, depth, merge_feat,
-                          (float*)saved, (float*)workspace, precision == N3DT_BF16, (hipStream_t)stream);
+                          (float*)saved, (float*)workspace, 0, (hipStream_t)stream);
     return check_hip("n3dt_render_train_fwd");
 }
 
@@ -258,9 +274,15 @@ extern "C" int n3dt_render_bwd(const N3dtGeom* g, int precision, const N3dtMlpPa
     if (saved_bytes < n3dt_render_train_saved_bytes(g)) return fail(N3DT_EWORKSPACE, "n3dt_render_bwd: saved buffer too small");
     if (workspace_bytes < n3dt_render_train_workspace_bytes(g)) return fail(N3DT_EWORKSPACE, "n3dt_render_bwd: workspace too small");
     if ((d_R || d_T) && (!xy || !R || !T || !Kinv)) return fail(N3DT_EINVAL, "n3dt_render_bwd: camera gradients need xy, R, T, Kinv");
+    if (precision == N3DT_BF16) {
+        if (d_R || d_T) return fail(N3DT_EINVAL, "n3dt_render_bwd: camera gradients are produced by the N3DT_F32 training path only");
+        n3dt_launch_train16_bwd(g, p, grads, shape, appea, audio, bg_featmap, d_merge_feat, d_fg_feat, d_bg_alpha, saved, d_bg_featmap,
+                                d_shape, d_appea, d_audio, workspace, (hipStream_t)stream);
+        return check_hip("n3dt_render_bwd");
+    }
     n3dt_launch_train_bwd(g, p, grads, shape, appea, audio, bg_featmap, d_merge_feat, d_fg_feat, d_bg_alpha, (const float*)saved,
-                          d_bg_featmap, d_shape, d_appea, d_audio, xy, R, T, Kinv, t_rand, d_R, d_T, (float*)workspace,
-                          precision == N3DT_BF16, (hipStream_t)stream);
+                          d_bg_featmap, d_shape, d_appea, d_audio, xy, R, T, Kinv, t_rand, d_R, d_T, (float*)workspace, 0,
+                          (hipStream_t)stream);
     return check_hip("n3dt_render_bwd");
 }
 

@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void ray_head_kernel(N3dtGeom g, int bpr, int 
                                                        const float* __restrict__ wlocal, const float* __restrict__ tail,
                                                        const float* __restrict__ bg_featmap, float* __restrict__ fg_feat,
                                                        float* __restrict__ bg_alpha, float* __restrict__ depth,
-                                                       float* __restrict__ weight, float* __restrict__ merge_feat) {
+                                                       float* __restrict__ weight, float* __restrict__ merge_feat,
+                                                       float* __restrict__ rayrec) {
     __shared__ float G[HEAD_RAYS][N3DT_G];
     __shared__ float pref[HEAD_RAYS][HEAD_MAX_BPR];
     __shared__ float wsum_s[HEAD_RAYS], dsum_s[HEAD_RAYS];
@@ -188,8 +189,17 @@ __global__ __launch_bounds__(256) void ray_head_kernel(N3dtGeom g, int bpr, int 
         if (rg < nrays_total)
             for (int k = 0; k < bpr; ++k) acc += pref[r][k] * part[((size_t)rg * bpr + k) * N3DT_PART_STRIDE + j];
         G[r][j] = acc;
+        // training: the per-ray record the head backward reads (composited RGB_layer_1 sums, sum of weights, depth, T)
+        if (rayrec && rg < nrays_total) rayrec[(size_t)rg * N3DT_PART_STRIDE + j] = acc;
     }
     __syncthreads();
+    if (rayrec && t < HEAD_RAYS && ray0 + t < nrays_total) {
+        float* rec = rayrec + (size_t)(ray0 + t) * N3DT_PART_STRIDE + N3DT_G;
+        rec[0] = wsum_s[t];
+        rec[1] = dsum_s[t];
+        rec[2] = 0.0f;
+        rec[3] = 0.0f;
+    }
     const float* W2T = tail;
     const float b2 = tail[N3DT_G * N3DT_C + t];
     float acc[HEAD_RAYS];
@@ -234,7 +244,17 @@ extern "C" void n3dt_launch_ray_head(const N3dtGeom* g, int bpr, int bs, const f
     const long nrays_total = (long)g->batch * g->n_rays;
     const int grid = (int)((nrays_total + HEAD_RAYS - 1) / HEAD_RAYS);
     hipLaunchKernelGGL(ray_head_kernel, dim3(grid), dim3(256), 0, stream, *g, bpr, bs, part, wlocal, tail,
-                       merge_feat ? bg_featmap : nullptr, fg_feat, bg_alpha, depth, weight, merge_feat);
+                       merge_feat ? bg_featmap : nullptr, fg_feat, bg_alpha, depth, weight, merge_feat, (float*)nullptr);
+}
+
+// training forward: also leaves the per-ray record [R][N3DT_PART_STRIDE] and the global sample weights behind
+extern "C" void n3dt_launch_ray_head_rec(const N3dtGeom* g, int bpr, int bs, const float* part, const float* wlocal,
+                                         const float* tail, const float* bg_featmap, float* fg_feat, float* bg_alpha, float* depth,
+                                         float* weight, float* merge_feat, float* rayrec, hipStream_t stream) {
+    const long nrays_total = (long)g->batch * g->n_rays;
+    const int grid = (int)((nrays_total + HEAD_RAYS - 1) / HEAD_RAYS);
+    hipLaunchKernelGGL(ray_head_kernel, dim3(grid), dim3(256), 0, stream, *g, bpr, bs, part, wlocal, tail,
+                       merge_feat ? bg_featmap : nullptr, fg_feat, bg_alpha, depth, weight, merge_feat, rayrec);
 }
 
 // [C][n] -> [n][C]

@@ -677,3 +677,5 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
     hipLaunchKernelGGL(train_fold_bwd_kernel, dim3(3, B), dim3(256), 0, s, *p, *gp, S, A, U, B, shape, appea, audio, dfold, d_shape,
                        d_appea, d_audio);
 }
+
+#include "train_x16.inc"

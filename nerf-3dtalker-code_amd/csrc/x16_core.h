@@ -1,0 +1,323 @@
+// Shared machinery of the 16-bit MFMA kernels (fused render forward, fused training forward / backward):
+// fragment traits, the LDS weight stream, the fast positional encoding and small compile-time helpers.
+#pragma once
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "n3dt_device.h"
+#include "n3dt_layout.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define X16_BS 32
+#define X16_CH 24                      // pieces per chunk (24 KiB)
+#define X16_PIECE 1024                 // bytes
+#define X16_NCHUNK (2280 / X16_CH)     // 48 + 6*288 + 336 + 24 + 144 pieces (RGB_layer_0 is merged into RGB_layer_1)
+#define X16_XT_TILES 98                // saved activation tiles per block (training): PE 2 + 8 hidden layers x 12
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+template <int PREC>
+struct X16;
+template <>
+struct X16<N3DT_BF16> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ frag pack(const float* v) {
+        frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (__bf16)v[j];
+        return f;
+    }
+    // ReLU on the packed 16-bit values: a signed 16-bit max with 0 (v_pk_max_i16) clears exactly
+    // the negative floats, and rounding commutes with it
+    // `lo` = 0: ReLU;  lo = -32768 (the most negative 16-bit pattern): identity -- lets one rolled loop body serve
+    // both the ReLU layers and the linear RGB_layer_0
+    static __device__ __forceinline__ frag relu(frag f, short lo) {
+        s16x8 s = __builtin_bit_cast(s16x8, f);
+        s = __builtin_elementwise_max(s, (s16x8)(lo));
+        return __builtin_bit_cast(frag, s);
+    }
+    // bias as an MFMA: A = [b_hi, b_lo, 0...] on the k = 0, 1 slots (lanes of the lower half), B = [1, 1, 0...]
+    static __device__ __forceinline__ frag bias_frag(float b, bool lower_half) {
+        __bf16 hi = (__bf16)b;
+        __bf16 lo = (__bf16)(b - (float)hi);
+        frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.0f;
+        if (lower_half) {
+            f[0] = hi;
+            f[1] = lo;
+        }
+        return f;
+    }
+    static __device__ __forceinline__ frag ones_frag() {
+        frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (__bf16)(j < 2 ? 1.0f : 0.0f);
+        return f;
+    }
+};
+template <>
+struct X16<N3DT_F16> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ frag pack(const float* v) {
+        frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (_Float16)v[j];
+        return f;
+    }
+    // `lo` = 0: ReLU;  lo = -32768 (the most negative 16-bit pattern): identity -- lets one rolled loop body serve
+    // both the ReLU layers and the linear RGB_layer_0
+    static __device__ __forceinline__ frag relu(frag f, short lo) {
+        s16x8 s = __builtin_bit_cast(s16x8, f);
+        s = __builtin_elementwise_max(s, (s16x8)(lo));
+        return __builtin_bit_cast(frag, s);
+    }
+    static __device__ __forceinline__ frag bias_frag(float b, bool lower_half) {
+        _Float16 hi = (_Float16)b;
+        _Float16 lo = (_Float16)(b - (float)hi);
+        frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (_Float16)0.0f;
+        if (lower_half) {
+            f[0] = hi;
+            f[1] = lo;
+        }
+        return f;
+    }
+    static __device__ __forceinline__ frag ones_frag() {
+        frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (_Float16)(j < 2 ? 1.0f : 0.0f);
+        return f;
+    }
+};
+
+// The weight stream: X16_NCHUNK chunks of X16_CH pieces, staged L2 -> LDS by LDS-DMA into a ring of three
+// chunk buffers (chunk c lives in buffer c % 3), and read by every wave through a small register ring of
+// X16_DEPTH fragments so that the matrix pipe never waits for an LDS round trip:
+//   * the prologue stages chunks 0 and 1 and meets once;
+//   * rendezvous n (one workgroup barrier) is met X16_DEPTH pieces BEFORE the end of chunk n: it makes chunk
+//     n+1 visible (issued at rendezvous n-1) and issues chunk n+2 into the buffer of chunk n-1, which every
+//     wave has left by then -- so fragment prefetches run across chunk boundaries without a bubble;
+//   * X16_STAGGER: waves WAVES/2.. (the SIMD partners of waves 0..) meet half a chunk earlier in THEIR stream,
+//     i.e. they run half a chunk behind, so one wave's accumulator epilogue overlaps its partner's MFMAs.
+#ifndef X16_STAGGER
+#define X16_STAGGER 0
+#endif
+#ifndef X16_DEPTH
+#define X16_DEPTH 2
+#endif
+#ifndef X16_DEFER
+#define X16_DEFER 0
+#endif
+#ifndef X16_DEFAULT_TILING
+#define X16_DEFAULT_TILING 1  // 1: 8 waves x 32 samples, 2: 4 waves x 64 samples (N3DT_X16_TILING overrides at run time)
+#endif
+#define X16_NBUF 3
+#define X16_CHUNK_BYTES (X16_CH * X16_PIECE)
+
+// Diagnostic build only (-DX16_STAMP): per-wave cycle sums of the three phases of a tile, written to the
+// `wlocal` debug buffer (never read by the library).  Not for timing the kernel: the stamps fence overlap.
+#ifdef X16_STAMP
+__device__ __forceinline__ unsigned long long x16_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define X16_T(x) x
+#else
+#define X16_T(x)
+#endif
+
+template <int PREC, int WAVES, int NCHUNK = X16_NCHUNK>
+struct WeightStream {
+    X16_T(unsigned long long t_rv = 0; unsigned long long t_mfma = 0; unsigned long long t_epi = 0; unsigned long long t_bias = 0;
+          int tile_no = 0; float* tl = nullptr;)
+    typedef typename X16<PREC>::frag frag;
+    const unsigned char* gsrc;  // per-lane: packed + (wave*PPW)*1KiB + lane*16
+    unsigned char* ring;        // LDS, 3 chunk buffers
+    unsigned lds_addr0;         // LDS byte address of ring + lane*16
+    unsigned cur_addr, nxt_addr;  // LDS byte addresses (+ lane*16) of the buffers of chunk `chunk` and `chunk`+1
+    int chunk;                  // chunk of the piece being consumed
+    int meets;                  // rendezvous done so far
+    int wave;
+    frag a[X16_DEPTH];          // piece p sits in a[p % X16_DEPTH]
+    static constexpr int PPW = X16_CH / WAVES;  // pieces each wave stages per chunk
+
+    __device__ __forceinline__ void issue(int c) {
+        const unsigned char* src = gsrc + (size_t)c * X16_CHUNK_BYTES;
+        unsigned char* dst = ring + (c % X16_NBUF) * X16_CHUNK_BYTES + wave * PPW * X16_PIECE;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + i * X16_PIECE), (LDS_AS void*)(dst + i * X16_PIECE), 16, 0,
+                                             0);
+    }
+    __device__ __forceinline__ void prologue_issue() {
+        issue(0);
+        issue(1);
+    }
+    __device__ __forceinline__ void prologue_wait() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        chunk = 0;
+        meets = 0;
+        cur_addr = lds_addr0;
+        nxt_addr = lds_addr0 + X16_CHUNK_BYTES;
+        preload<0>();
+    }
+    template <int J>
+    __device__ __forceinline__ void preload() {
+        if constexpr (J < X16_DEPTH - 1) {
+            read_frag<J * X16_PIECE>(a[J], cur_addr);
+            preload<J + 1>();
+        }
+    }
+    __device__ __forceinline__ void rendezvous() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk meets+1 have landed
+        __syncthreads();                                   // everyone's have; everyone has left chunk meets-1
+        if (meets + 2 < NCHUNK) issue(meets + 2);
+        ++meets;
+    }
+    // The fragment reads are issued from inline asm so that their completion can be awaited with a COUNTED
+    // s_waitcnt lgkmcnt(DEPTH-1): hipcc's own bookkeeping waits lgkmcnt(0) here, i.e. for the prefetch it has just
+    // issued, which puts a full LDS round trip in front of every other MFMA (45 % of the wave time parked).
+    // LDS returns in order, so "at most DEPTH-1 younger operations outstanding" means this piece has landed; younger
+    // compiler-issued LDS operations only make the wait more conservative.  The wait names the fragment as "+v", so
+    // the consuming MFMA cannot be scheduled above it.
+    template <int OFF>
+    __device__ __forceinline__ void read_frag(frag& dst, const unsigned addr) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
+    }
+    __device__ __forceinline__ void await_frag(frag& f) {
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "i"(X16_DEPTH - 1));
+    }
+    // Fragment of stage-local piece P (stages are whole chunks, so P % X16_CH and P % X16_DEPTH equal their
+    // stream-global values).  LAST/NP: the final stage must not prefetch past the end of the stream.
+    template <bool LATE, bool LAST, int NP, int P>
+    __device__ __forceinline__ frag next() {
+        constexpr int rv = (LATE ? X16_CH / 2 : X16_CH) - X16_DEPTH;
+        if (P % X16_CH == rv) {
+            X16_T(const unsigned long long r0 = x16_now();)
+            rendezvous();
+            X16_T(t_rv += x16_now() - r0;)
+        }
+        constexpr int Q = P + X16_DEPTH - 1;
+        if (!(LAST && Q >= NP)) {
+            const unsigned addr = (Q % X16_CH < P % X16_CH) ? nxt_addr : cur_addr;
+            read_frag<(Q % X16_CH) * X16_PIECE>(a[Q % X16_DEPTH], addr);
+        }
+        await_frag(a[P % X16_DEPTH]);
+        const frag r = a[P % X16_DEPTH];
+        if ((P + 1) % X16_CH == 0) {
+            ++chunk;
+            cur_addr = nxt_addr;
+            nxt_addr = lds_addr0 + ((chunk + 1) % X16_NBUF) * X16_CHUNK_BYTES;
+        }
+        return r;
+    }
+};
+
+// positional-encoding channel `ch` (0..63) via v_sin_f32 on a two-term phase in revolutions.  The three
+// coordinates travel as separate scalars and are picked with selects: with float[3] arguments hipcc turned the
+// runtime `dim` into an index into a private-memory copy (28 B/lane of scratch, 117 MB of traffic per launch).
+__device__ __forceinline__ float pick3(const int d, const float a, const float b, const float c) {
+    const float ab = d == 0 ? a : b;
+    return d == 2 ? c : ab;
+}
+__device__ __forceinline__ float pe_fast(const float p0, const float p1, const float p2, const float h0, const float h1,
+                                         const float h2, const float l0, const float l1, const float l2, const int ch) {
+    const int cc = ch < 3 ? 0 : ch - 3;
+    const int k = cc / 6, w = cc % 6, dim = w >= 3 ? w - 3 : w;
+    const float sc = (float)(1 << k);
+    const float hi = pick3(dim, h0, h1, h2), lo = pick3(dim, l0, l1, l2);
+    const float r = __builtin_amdgcn_fractf(hi * sc) + lo * sc + (w >= 3 ? 0.25f : 0.0f);  // cos x = sin(x + pi/2)
+    const float sv = __builtin_amdgcn_sinf(r);
+    const float raw = pick3(ch, p0, p1, p2);
+    return ch < 3 ? raw : (ch >= N3DT_PE_DIM ? 0.0f : sv);
+}
+
+enum { MODE_HIDDEN = 0, MODE_LINEAR = 1, MODE_DENSITY = 2, MODE_COMPOSITE = 3 };
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N) -- the piece index has to reach the
+// inline-asm immediates as a constant expression
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// sum over the 32 lanes of a half-wave of 32 per-lane values: lane c ends with value index rev5(c)
+__device__ __forceinline__ float butterfly32(float (&v)[32], const int c) {
+#pragma unroll
+    for (int step = 0; step < 5; ++step) {
+        const int m = 16 >> step;
+        const bool bit = (c & m) != 0;
+        const int n = 32 >> step;
+#pragma unroll
+        for (int i = 0; i < n / 2; ++i) {
+            float keep = bit ? v[2 * i + 1] : v[2 * i];
+            float send = bit ? v[2 * i] : v[2 * i + 1];
+            v[i] = keep + __shfl_xor(send, m, 64);
+        }
+    }
+    return v[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transposing a packed tile with the matrix pipe (training path).
+//
+// A 32x32 tile in "lane = sample" form is two fragments f0, f1: lane (c, h) element j of f_s holds
+// X[channel 16s + 8(j>>2) + 4h + (j&3)][sample c] (the B-operand form the fused kernels keep activations in).
+// Taken as the A operand against the selection fragments I_0, I_1 below, two MFMAs return X^T in accumulator
+// layout (lane = channel, registers = samples); packed, that is the tile in "lane = channel" form, two 1 KiB
+// pieces P_0, P_1: lane (r, h) element j of P_s holds X[channel r][sample 16s + 8(j>>2) + 4h + (j&3)] -- the
+// operand form of a product that sums over SAMPLES (the weight gradients dW = dZ^T X), with the same sample
+// permutation for every tensor.  The same two selection fragments turn pieces back into an accumulator-layout
+// tile (lane = sample) -- used for the ReLU gates of the backward chain.  Exact: x * 1.0 summed with zeros.
+// ---------------------------------------------------------------------------------------------
+template <int PREC>
+__device__ __forceinline__ typename X16<PREC>::frag x16_ident_frag(const int s, const int lane) {
+    const int c = lane & 31, h = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (c == 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) ? 1.0f : 0.0f;
+    return X16<PREC>::pack(v);
+}
+
+template <int PREC>
+__device__ __forceinline__ f32x16 x16_transpose_tile(const typename X16<PREC>::frag f0, const typename X16<PREC>::frag f1,
+                                                     const typename X16<PREC>::frag I0, const typename X16<PREC>::frag I1) {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+    z = X16<PREC>::mfma(f0, I0, z);
+    return X16<PREC>::mfma(f1, I1, z);
+}
+
+// lane = sample tile (f0, f1) -> two lane = channel pieces at dst (per-lane pointer, lane * 16 included), 1 KiB apart
+template <int PREC>
+__device__ __forceinline__ void x16_transpose_store(const typename X16<PREC>::frag f0, const typename X16<PREC>::frag f1,
+                                                    const typename X16<PREC>::frag I0, const typename X16<PREC>::frag I1,
+                                                    unsigned char* dst) {
+    typedef typename X16<PREC>::frag frag;
+    const f32x16 t = x16_transpose_tile<PREC>(f0, f1, I0, I1);
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = t[r];
+    *reinterpret_cast<frag*>(dst) = X16<PREC>::pack(v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = t[8 + r];
+    *reinterpret_cast<frag*>(dst + X16_PIECE) = X16<PREC>::pack(v);
+}

@@ -147,8 +147,8 @@ def _bytes_or_raise(n, what):
     return n
 
 
-def render_train_fwd(geom, packed_f32, params, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap, precision=0):
-    """Forward with saved activations.  Returns (out dict, saved buffer)."""
+def render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap, precision=0):
+    """Forward with saved activations.  `packed` = pack_mlp(...) of the same precision.  Returns (out dict, saved buffer)."""
     dev = xy.device
     B, Nr, C = geom.batch, geom.n_rays, geom.feat_nc
     out = {
@@ -161,7 +161,7 @@ def render_train_fwd(geom, packed_f32, params, xy, R, T, Kinv, shape, appea, aud
     saved = torch.empty(sbytes, dtype=torch.uint8, device=dev)
     ws = WORKSPACE.get("train", wbytes, dev)
     check(lib().n3dt_render_train_fwd(
-        ctypes.byref(geom), precision, _ptr(packed_f32), ctypes.byref(params), _ptr(xy), _ptr(R), _ptr(T), _ptr(Kinv), _ptr(shape), _ptr(appea),
+        ctypes.byref(geom), precision, _ptr(packed), ctypes.byref(params), _ptr(xy), _ptr(R), _ptr(T), _ptr(Kinv), _ptr(shape), _ptr(appea),
         _ptr(audio), _ptr(t_rand), _ptr(bg_featmap), _ptr(out["fg_feat"]), _ptr(out["bg_alpha"]), None, _ptr(out["merge_feat"]),
         _ptr(saved), sbytes, _ptr(ws), wbytes, _stream()), "n3dt_render_train_fwd")
     return out, saved
