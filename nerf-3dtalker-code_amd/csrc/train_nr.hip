@@ -338,6 +338,54 @@ __global__ void nrt_rgb_bias_kernel(int nb, int HW, const float* __restrict__ d_
     if (threadIdx.x == 0) atomicAdd(&db[c], red[0]);
 }
 
+// feat_2_rgb weight gradient: dW[k][c] += sum over images and pixels of d_rgb[img][k][pix] * net[img][pix][c]
+// (a 3 x co result over up to 10^6 pixels: a reduction, not a GEMM).  Thread = 4 adjacent channels x one pixel lane;
+// block = NRT_WG_PIX consecutive pixels of one image; co in {32, 64, 128, 256}.
+#define NRT_WG_PIX 2048
+__global__ __launch_bounds__(256) void nrt_to_rgb_wgrad_kernel(int HW, int co, const float* __restrict__ d_rgb,
+                                                               const float* __restrict__ net, float* __restrict__ dW) {
+    __shared__ float red[256][13];
+    const int cg = co >> 2, lanes = 256 / cg;
+    const int t = threadIdx.x, c4 = (t % cg) * 4, pl = t / cg;
+    const int chunks = (HW + NRT_WG_PIX - 1) / NRT_WG_PIX;
+    const int img = blockIdx.x / chunks, p0 = (blockIdx.x % chunks) * NRT_WG_PIX;
+    const int p1 = min(HW, p0 + NRT_WG_PIX);
+    const float* d = d_rgb + (size_t)img * 3 * HW;
+    const float* x = net + (size_t)img * HW * co + c4;
+    float acc[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] = 0.0f;
+    for (int p = p0 + pl; p < p1; p += lanes) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)p * co);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float g = d[(size_t)k * HW + p];
+            acc[k][0] = fmaf(g, v.x, acc[k][0]);
+            acc[k][1] = fmaf(g, v.y, acc[k][1]);
+            acc[k][2] = fmaf(g, v.z, acc[k][2]);
+            acc[k][3] = fmaf(g, v.w, acc[k][3]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[t][k * 4 + j] = acc[k][j];
+    __syncthreads();
+    // thread (k, channel) sums the pixel lanes
+    for (int o = t; o < 3 * co; o += 256) {
+        const int k = o / co, c = o % co;
+        float sum = 0.0f;
+        for (int l = 0; l < lanes; ++l) sum += red[l * cg + (c >> 2)][k * 4 + (c & 3)];
+        atomicAdd(&dW[(size_t)k * co + c], sum);
+    }
+}
+static void launch_to_rgb_wgrad(int nb, int HW, int co, const float* d_rgb, const float* net, float* dW, hipStream_t s) {
+    const int chunks = (HW + NRT_WG_PIX - 1) / NRT_WG_PIX;
+    hipLaunchKernelGGL(nrt_to_rgb_wgrad_kernel, dim3(nb * chunks), dim3(256), 0, s, HW, co, d_rgb, net, dW);
+}
+
 #define GRID1(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256)
 
 static Gemm32 mk(int M, int N, int K, const float* A, long lda, int ak, const float* B, long ldb, int bk, float* C, long ldc) {
@@ -352,15 +400,15 @@ static Gemm32 mk(int M, int N, int K, const float* A, long lda, int ak, const fl
     g.accumulate = 0; g.split_k = 1;
     return g;
 }
-static int split_for(long K);
-// parameter-gradient products always ADD into their destination: atomics when K is split, += otherwise
+// parameter-gradient products always ADD into their destination: atomics when K is split, += otherwise.
+// The K (pixel) dimension is split so that the launch has about 1024 workgroups, at least 512 pixels each.
 static void set_grad_split(Gemm32& q, long K) {
-    q.split_k = split_for(K);
+    const long tiles = (long)((q.M + 127) / 128) * ((q.N + 127) / 128);
+    long s = 1024 / tiles, cap = K / 512;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    q.split_k = (int)s;
     q.accumulate = q.split_k <= 1 ? 1 : 0;
-}
-static int split_for(long K) {
-    long s = K / 2048;
-    return (int)(s < 1 ? 1 : (s > 128 ? 128 : s));
 }
 
 // featmap [nb][fs*fs][C] -> img [nb,3,P,P]; all intermediates kept in `saved`
@@ -423,11 +471,7 @@ extern "C" void n3dt_launch_nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderPa
         const float* x = i == 0 ? featmap : saved + sv.net[i - 1];
         const float* net = saved + sv.net[i];
         // rgb = rgb_prev_up + feat_2_rgb[i+1](net): parameter grads, then d net (gated by lrelu'(net))
-        for (int im = 0; im < nb; ++im) {
-            Gemm32 w = mk(3, co, HW, drgb + (size_t)im * 3 * HW, HW, 0, net + (size_t)im * HW * co, co, 1, gp->to_rgb_w[i + 1], co);
-            set_grad_split(w, HW);
-            n3dt_gemm(w, bf16, s);
-        }
+        launch_to_rgb_wgrad(nb, HW, co, drgb, net, gp->to_rgb_w[i + 1], s);
         hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[i + 1]);
         // d net: from the rgb branch (+ from the next stage's input gradient, already in dnet when i < nblk-1)
         if (i == nblk - 1) {
@@ -486,11 +530,7 @@ extern "C" void n3dt_launch_nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderPa
         const int fs = g->featmap_size, HW = fs * fs;
         hipLaunchKernelGGL(nrt_blur_adj_planar_kernel, GRID1((size_t)nb * 3 * 4 * HW), 0, s, nb * 3, 2 * fs, 2 * fs, drgb, dtmp);
         hipLaunchKernelGGL(nrt_bilinear_adj_kernel, GRID1((size_t)nb * 3 * HW), 0, s, nb * 3, fs, fs, dtmp, drgb);
-        for (int im = 0; im < nb; ++im) {
-            Gemm32 w = mk(3, C, HW, drgb + (size_t)im * 3 * HW, HW, 0, featmap + (size_t)im * HW * C, C, 1, gp->to_rgb_w[0], C);
-            set_grad_split(w, HW);
-            n3dt_gemm(w, bf16, s);
-        }
+        launch_to_rgb_wgrad(nb, HW, C, drgb, featmap, gp->to_rgb_w[0], s);
         hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[0]);
         hipLaunchKernelGGL(nrt_to_rgb_bwd_kernel, GRID1((size_t)nb * HW * (C / 4)), 3 * C * sizeof(float), s, nb, HW, C, drgb,
                            p->to_rgb_w[0], (const float*)nullptr, dnet, 1);
