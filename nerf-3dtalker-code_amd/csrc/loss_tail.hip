@@ -41,13 +41,15 @@ __global__ void loss_tail_fwd_kernel(int B, int HW, const float* __restrict__ me
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
         vals[k] = x;
     }
+    // one atomic per value and workgroup: thousands of same-address atomics serialise (0.5 ms at 512^2 before this)
+    __shared__ float red[4][5];
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&acc[0], vals[0]);
-        atomicAdd(&acc[1], vals[1]);
-        atomicAdd(&acc[2], vals[2]);
-        atomicAdd(&acc[3], vals[3]);
-        atomicAdd(&acc[4], vals[4]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) red[wave][k] = vals[k];
     }
+    __syncthreads();
+    if (threadIdx.x < 5) atomicAdd(&acc[threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 // terms[3] = { bg_loss, head_loss, nonhead_loss }
@@ -82,7 +84,7 @@ extern "C" void n3dt_launch_loss_fwd(int B, int HW, const float* merge, const fl
     (void)hipMemsetAsync(acc, 0, 6 * sizeof(float), s);
     const size_t n = (size_t)B * 3 * HW;
     int grid = (int)((n + 255) / 256);
-    if (grid > 2048) grid = 2048;
+    if (grid > 512) grid = 512;
     hipLaunchKernelGGL(loss_tail_fwd_kernel, dim3(grid), dim3(256), 0, s, B, HW, merge, bg, gt, mask, v, acc);
     hipLaunchKernelGGL(loss_tail_finish_kernel, dim3(1), dim3(1), 0, s, HW, acc, terms);
 }

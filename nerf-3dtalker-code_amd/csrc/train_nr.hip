@@ -294,30 +294,39 @@ __global__ void nrt_add_kernel(size_t n, const float* __restrict__ a, float* __r
 }
 
 // out[n] += sum_m X[m][n]: one thread = 4 adjacent columns x a 256-row chunk, 8 independent float4 loads in flight
-__global__ void nrt_colsum_kernel(const float* __restrict__ X, long ldx, long rows, int N, float* __restrict__ out) {
-    const int t = threadIdx.x;
-    if (4 * t >= N) return;  // every N here is a multiple of 32
-    const long r0 = (long)blockIdx.x * 256, r1 = min(rows, r0 + 256);
-    const float* base = X + 4 * t;
+#define NRT_CS_ROWS 1024
+__global__ __launch_bounds__(256) void nrt_colsum_kernel(const float* __restrict__ X, long ldx, long rows, int N, float* __restrict__ out) {
+    // thread = 4 adjacent columns x one row lane (256 / (N/4) row lanes; every N here is a multiple of 32, <= 1024)
+    __shared__ f32x4 red[256];
+    const int cg = N >> 2, lanes = 256 / cg;
+    const int t = threadIdx.x, cq = t % cg, rl = t / cg;
+    const long r0 = (long)blockIdx.x * NRT_CS_ROWS, r1 = min(rows, r0 + NRT_CS_ROWS);
+    const float* base = X + 4 * cq;
     f32x4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    long r = r0;
-    for (; r + 8 <= r1; r += 8) {
-        f32x4 v[8];
+    long r = r0 + rl;
+    if (rl < lanes) {
+        for (; r + 3L * lanes < r1; r += 4L * lanes) {
+            f32x4 v[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (r + u) * ldx);
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (r + (long)u * lanes) * ldx);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u & 3] += v[u];
+            for (int u = 0; u < 4; ++u) acc[u] += v[u];
+        }
+        for (; r < r1; r += lanes) acc[0] += *reinterpret_cast<const f32x4*>(base + r * ldx);
     }
-    for (; r < r1; ++r) acc[0] += *reinterpret_cast<const f32x4*>(base + r * ldx);
-    const f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    red[t] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (t < cg) {
+        f32x4 sum = red[t];
+        for (int l = 1; l < lanes; ++l) sum += red[l * cg + t];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) atomicAdd(&out[4 * t + j], s[j]);
+        for (int j = 0; j < 4; ++j) atomicAdd(&out[4 * t + j], sum[j]);
+    }
 }
 static void launch_nrt_colsum(const float* X, long ldx, long rows, int N, float* out, hipStream_t s) {
-    const int threads = ((N / 4 + 63) / 64) * 64;
-    hipLaunchKernelGGL(nrt_colsum_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(threads), 0, s, X, ldx, rows, N, out);
+    hipLaunchKernelGGL(nrt_colsum_kernel, dim3((unsigned)((rows + NRT_CS_ROWS - 1) / NRT_CS_ROWS)), dim3(256), 0, s, X, ldx, rows, N, out);
 }
 
 // db[c] += sum over images and pixels of planar d_rgb
