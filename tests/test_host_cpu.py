@@ -35,6 +35,11 @@ def test_geometry_validation_without_a_gpu():
     assert L.n3dt_render_workspace_bytes(ctypes.byref(bad), _lib.BF16) == 0
     assert b"384" in L.n3dt_last_error()
     assert L.n3dt_neural_render_workspace_bytes(ctypes.byref(g), 3) > 0
+    # training buffers: one size serves both precisions, and it covers the fused bf16 path's per-block records
+    # (98 saved + 103 gradient tiles of 2 KiB per 32-sample block)
+    blocks = 64 * 1
+    assert L.n3dt_render_train_saved_bytes(ctypes.byref(g)) >= blocks * 98 * 2048
+    assert L.n3dt_render_train_workspace_bytes(ctypes.byref(g)) >= blocks * 103 * 2048
 
 
 def test_state_dict_inventory_matches_reference_keys():
