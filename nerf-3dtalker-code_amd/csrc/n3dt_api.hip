@@ -3,6 +3,7 @@
 // caller's stream.  No allocation, no synchronisation, no global mutable state.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/n3dt.h"
@@ -18,6 +19,8 @@ void n3dt_launch_nerf_fwd_f32(const N3dtGeom*, const N3dtMlpParams*, const void*
                               const float*, const float*, const float*, float*, float*, hipStream_t);
 void n3dt_launch_nerf_fwd_x16(const N3dtGeom*, int, const void*, const float*, const float*, const float*, const float*,
                               const float*, const float*, float*, float*, hipStream_t);
+void n3dt_launch_nerf_fwd_x16b(const N3dtGeom*, int, const void*, const float*, const float*, const float*, const float*,
+                               const float*, const float*, float*, float*, hipStream_t);
 size_t n3dt_nr_workspace_floats(const N3dtGeom*, int);
 size_t n3dt_train_saved_floats(const N3dtGeom*);
 size_t n3dt_train_ws_floats(const N3dtGeom*);
@@ -72,6 +75,19 @@ static int check_geom(const N3dtGeom* g, int precision) {
     if (g->shape_dim < 1 || g->appea_dim < 1 || g->audio_dim < 0) return fail(N3DT_EINVAL, "bad latent widths");
     if (g->shape_dim + g->audio_dim > 512 || g->appea_dim > 512) return fail(N3DT_EINVAL, "latent width > 512");
     return N3DT_OK;
+}
+
+// Tiling of the 16-bit fused render kernel: 1 = 32x32x16 MFMA, 8 waves x 32 samples; 2 = the same, 4 waves x 64 samples;
+// 3 = 16x16x32 MFMA, 8 waves x 32 samples (nerf_fwd_x16b.hip).  N3DT_X16_TILING overrides the default at run time.
+#ifndef N3DT_X16_DEFAULT_TILING
+#define N3DT_X16_DEFAULT_TILING 1
+#endif
+static int x16_tiling() {
+    static const int t = [] {
+        const char* e = getenv("N3DT_X16_TILING");
+        return e ? atoi(e) : N3DT_X16_DEFAULT_TILING;
+    }();
+    return t;
 }
 
 static inline int block_samples(int precision) { return precision == N3DT_F32 ? 16 : 32; }
@@ -170,6 +186,9 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_n], s);
     if (precision == N3DT_F32)
         n3dt_launch_nerf_fwd_f32(g, p, packed_mlp, fold, xy, R, T, Kinv, t_rand, part, weight ? wlocal : nullptr, s);
+    else if (x16_tiling() == 3)
+        n3dt_launch_nerf_fwd_x16b(g, precision, (const unsigned char*)packed_mlp + n3dt_packed_region_b_offset(precision), fold, xy, R, T,
+                                  Kinv, t_rand, part, weight ? wlocal : nullptr, s);
     else
         n3dt_launch_nerf_fwd_x16(g, precision, packed_mlp, fold, xy, R, T, Kinv, t_rand, part, weight ? wlocal : nullptr, s);
     if (prof) {

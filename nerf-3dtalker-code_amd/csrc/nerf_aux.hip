@@ -34,7 +34,9 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
 // two layers (models.py:79-81), so W_m = Wr1[:, 0:384] . Wr0 (192 x 384) replaces 12 + 6 out tiles by 6.  It is
 // stored at stage 9's offset (right behind the density stage, keeping the stream contiguous); stage 10's slot stays
 // unused.  The exact-fp32 kernel keeps the two layers separate (the reference's operation order).
-__global__ void pack_mlp_kernel(N3dtMlpParams p, int precision, int S, int A, int U, unsigned char* __restrict__ out) {
+// `order16` (16-bit precisions): 0 = 32x32x16 fragment order above, 1 = 16x16x32 order (nerf_fwd_x16b.hip):
+//   e = ((t*(K/32) + ks)*64 + lane)*8 + j  ->  W'[t*16 + (lane&15)][32*ks + 16*(j>>2) + 4*(lane>>4) + (j&3)]
+__global__ void pack_mlp_kernel(N3dtMlpParams p, int precision, int order16, int S, int A, int U, unsigned char* __restrict__ out) {
     const int stage = blockIdx.y;
     const bool merged = precision != N3DT_F32 && stage == 9;
     if (precision != N3DT_F32 && stage == 10) return;
@@ -50,12 +52,18 @@ __global__ void pack_mlp_kernel(N3dtMlpParams p, int precision, int S, int A, in
             int k4 = (int)(t % (st.K / 16)), ot = (int)(t / (st.K / 16));
             row = ot * 16 + (lane & 15);
             col = 16 * k4 + 4 * j + (lane >> 4);
-        } else {
+        } else if (order16 == 0) {
             int j = e & 7, lane = (e >> 3) & 63;
             size_t t = e >> 9;
             int ks = (int)(t % (st.K / 16)), ot = (int)(t / (st.K / 16));
             row = ot * 32 + (lane & 31);
             col = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+        } else {
+            int j = e & 7, lane = (e >> 3) & 63;
+            size_t t = e >> 9;
+            int ks = (int)(t % (st.K / 32)), ot = (int)(t / (st.K / 32));
+            row = ot * 16 + (lane & 15);
+            col = 32 * ks + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
         }
         float v;
         if (merged) {
@@ -88,8 +96,11 @@ __global__ void pack_tail_kernel(N3dtMlpParams p, float* __restrict__ tail) {
 }
 
 extern "C" void n3dt_launch_pack(const N3dtGeom* g, int precision, const N3dtMlpParams* p, void* packed, hipStream_t stream) {
-    hipLaunchKernelGGL(pack_mlp_kernel, dim3(64, N3DT_NSTAGE), dim3(256), 0, stream, *p, precision, g->shape_dim, g->appea_dim,
+    hipLaunchKernelGGL(pack_mlp_kernel, dim3(64, N3DT_NSTAGE), dim3(256), 0, stream, *p, precision, 0, g->shape_dim, g->appea_dim,
                        g->audio_dim, reinterpret_cast<unsigned char*>(packed));
+    if (precision != N3DT_F32)
+        hipLaunchKernelGGL(pack_mlp_kernel, dim3(64, N3DT_NSTAGE), dim3(256), 0, stream, *p, precision, 1, g->shape_dim, g->appea_dim,
+                           g->audio_dim, reinterpret_cast<unsigned char*>(packed) + n3dt_packed_region_b_offset(precision));
     float* tail = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(packed) + n3dt_packed_tail_offset(precision));
     const int n = N3DT_G * N3DT_C + N3DT_C;
     hipLaunchKernelGGL(pack_tail_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, *p, tail);

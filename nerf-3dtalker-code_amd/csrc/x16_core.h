@@ -26,6 +26,9 @@ struct X16<N3DT_BF16> {
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 mfma16(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
     static __device__ __forceinline__ frag pack(const float* v) {
         frag f;
 #pragma unroll
@@ -66,6 +69,9 @@ struct X16<N3DT_F16> {
     typedef f16x8 frag;
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ frag pack(const float* v) {
         frag f;
