@@ -111,6 +111,22 @@ __device__ __forceinline__ float n3dt_pe_row_accurate(const float p[3], int row)
     return w < 3 ? sinf(a) : cosf(a);
 }
 
+// Division of an element index by an extent that is a power of two in every shipped configuration (channel counts,
+// map sizes): shift and mask when it is, the general division otherwise.  A runtime 64-bit division costs ~100 VALU
+// operations -- per-element kernels that decompose their index with five of them are bound by that, not by memory.
+struct N3dtDiv {
+    unsigned d;
+    int sh;  // log2(d) when d is a power of two, else -1
+};
+__device__ __forceinline__ N3dtDiv n3dt_div(const unsigned d) {
+    N3dtDiv v;
+    v.d = d;
+    v.sh = (d != 0 && (d & (d - 1)) == 0) ? 31 - __builtin_clz(d) : -1;
+    return v;
+}
+__device__ __forceinline__ size_t n3dt_quot(const size_t x, const N3dtDiv v) { return v.sh >= 0 ? x >> v.sh : x / v.d; }
+__device__ __forceinline__ int n3dt_rem(const size_t x, const N3dtDiv v) { return v.sh >= 0 ? (int)(x & (v.d - 1)) : (int)(x % v.d); }
+
 // exclusive prefix product over `width` consecutive lanes (width 16 or 32, power of two)
 template <int WIDTH>
 __device__ __forceinline__ float n3dt_exclusive_prod(float x, int lane_in_group) {

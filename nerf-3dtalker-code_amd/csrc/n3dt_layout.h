@@ -50,7 +50,8 @@ __host__ __device__ inline size_t n3dt_stage_offset(int s) {
 __host__ __device__ inline size_t n3dt_packed_matrix_elems() { return n3dt_stage_offset(N3DT_NSTAGE); }
 
 // the fp32 tail that follows the matrices in every precision: W2^T [192][256], b2 [256]
-__host__ __device__ inline size_t n3dt_packed_tail_floats() { return (size_t)192 * 256 + 256; }
+// (+ the fp32 merged RGB matrix W_m [192][384] the 16-bit matrices are packed from)
+__host__ __device__ inline size_t n3dt_packed_tail_floats() { return (size_t)192 * 256 + 256 + (size_t)192 * 384; }
 
 __host__ __device__ inline size_t n3dt_packed_elem_bytes(int precision) { return precision == 0 ? 4 : 2; }
 

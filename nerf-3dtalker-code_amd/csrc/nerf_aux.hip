@@ -25,6 +25,50 @@ __device__ __forceinline__ float logical_weight(const N3dtMlpParams& p, int stag
     }
 }
 
+// C[m][n] (+)= sum_k A(m,k) B(n,k) for small products (operands given by element strides; fp32 FMA): the merged
+// RGB matrix W_m = Wr1[:, 0:384] Wr0 of the 16-bit kernels and its un-merge in the training backward.
+// 32 x 32 tile per 256-thread workgroup, 2 x 2 results per thread -- a few hundred workgroups where the generic
+// 128 x 128 GEMM would launch six.
+__global__ __launch_bounds__(256) void small_gemm_kernel(int M, int N, int K, const float* __restrict__ A, long sam, long sak,
+                                                                 const float* __restrict__ Bm, long sbn, long sbk,
+                                                                 float* __restrict__ C, long ldc, int accumulate) {
+    __shared__ float As[32][33], Bs[32][33];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        for (int i = t; i < 1024; i += 256) {
+            // pick the index that is contiguous in memory as the fast one
+            const int a_r = sak == 1 ? i >> 5 : i & 31, a_k = sak == 1 ? i & 31 : i >> 5;
+            const int b_r = sbk == 1 ? i >> 5 : i & 31, b_k = sbk == 1 ? i & 31 : i >> 5;
+            As[a_k][a_r] = (m0 + a_r < M && k0 + a_k < K) ? A[(long)(m0 + a_r) * sam + (long)(k0 + a_k) * sak] : 0.0f;
+            Bs[b_k][b_r] = (n0 + b_r < N && k0 + b_k < K) ? Bm[(long)(n0 + b_r) * sbn + (long)(k0 + b_k) * sbk] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const float a0 = As[k][ty], a1 = As[k][ty + 16], b0 = Bs[k][tx], b1 = Bs[k][tx + 16];
+            acc[0][0] = fmaf(a0, b0, acc[0][0]);
+            acc[0][1] = fmaf(a0, b1, acc[0][1]);
+            acc[1][0] = fmaf(a1, b0, acc[1][0]);
+            acc[1][1] = fmaf(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
+            if (m < M && n < N) C[(long)m * ldc + n] = (accumulate ? C[(long)m * ldc + n] : 0.0f) + acc[i][j];
+        }
+}
+extern "C" void n3dt_launch_small_gemm(int M, int N, int K, const float* A, long sam, long sak, const float* B, long sbn, long sbk,
+                                       float* C, long ldc, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, s, M, N, K, A, sam, sak, B, sbn, sbk, C, ldc,
+                       accumulate);
+}
+
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
     __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
     return __builtin_bit_cast(unsigned short, h);
@@ -36,7 +80,8 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
 // unused.  The exact-fp32 kernel keeps the two layers separate (the reference's operation order).
 // `order16` (16-bit precisions): 0 = 32x32x16 fragment order above, 1 = 16x16x32 order (nerf_fwd_x16b.hip):
 //   e = ((t*(K/32) + ks)*64 + lane)*8 + j  ->  W'[t*16 + (lane&15)][32*ks + 16*(j>>2) + 4*(lane>>4) + (j&3)]
-__global__ void pack_mlp_kernel(N3dtMlpParams p, int precision, int order16, int S, int A, int U, unsigned char* __restrict__ out) {
+__global__ void pack_mlp_kernel(N3dtMlpParams p, int precision, int order16, int S, int A, int U, const float* __restrict__ wm,
+                                unsigned char* __restrict__ out) {
     const int stage = blockIdx.y;
     const bool merged = precision != N3DT_F32 && stage == 9;
     if (precision != N3DT_F32 && stage == 10) return;
@@ -67,9 +112,7 @@ __global__ void pack_mlp_kernel(N3dtMlpParams p, int precision, int order16, int
         }
         float v;
         if (merged) {
-            const float* w1 = p.weight[10] + (size_t)row * (N3DT_HID + A);
-            v = 0.0f;
-            for (int j = 0; j < N3DT_HID; ++j) v = fmaf(w1[j], p.weight[9][(size_t)j * N3DT_HID + col], v);
+            v = wm[(size_t)row * N3DT_HID + col];
         } else {
             v = logical_weight(p, stage, row, col, S, A, U);
         }
@@ -96,12 +139,16 @@ __global__ void pack_tail_kernel(N3dtMlpParams p, float* __restrict__ tail) {
 }
 
 extern "C" void n3dt_launch_pack(const N3dtGeom* g, int precision, const N3dtMlpParams* p, void* packed, hipStream_t stream) {
+    float* tail = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(packed) + n3dt_packed_tail_offset(precision));
+    // the merged RGB matrix W_m = Wr1[:, 0:384] Wr0 (fp32, behind W2^T and b2) is formed once and packed from there
+    float* wm = tail + N3DT_G * N3DT_C + N3DT_C;
+    if (precision != N3DT_F32)
+        n3dt_launch_small_gemm(192, 384, 384, p->weight[10], 384 + g->appea_dim, 1, p->weight[9], 1, 384, wm, 384, 0, stream);
     hipLaunchKernelGGL(pack_mlp_kernel, dim3(64, N3DT_NSTAGE), dim3(256), 0, stream, *p, precision, 0, g->shape_dim, g->appea_dim,
-                       g->audio_dim, reinterpret_cast<unsigned char*>(packed));
+                       g->audio_dim, wm, reinterpret_cast<unsigned char*>(packed));
     if (precision != N3DT_F32)
         hipLaunchKernelGGL(pack_mlp_kernel, dim3(64, N3DT_NSTAGE), dim3(256), 0, stream, *p, precision, 1, g->shape_dim, g->appea_dim,
-                           g->audio_dim, reinterpret_cast<unsigned char*>(packed) + n3dt_packed_region_b_offset(precision));
-    float* tail = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(packed) + n3dt_packed_tail_offset(precision));
+                           g->audio_dim, wm, reinterpret_cast<unsigned char*>(packed) + n3dt_packed_region_b_offset(precision));
     const int n = N3DT_G * N3DT_C + N3DT_C;
     hipLaunchKernelGGL(pack_tail_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, *p, tail);
 }

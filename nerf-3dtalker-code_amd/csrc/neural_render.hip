@@ -82,9 +82,11 @@ __global__ void blur_nhwc_kernel(int nb, int H, int W, int C, const float* __res
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t total = (size_t)nb * H * W * c4;
     if (i >= total) return;
-    int cq = (int)(i % c4);
-    size_t pix = i / c4;
-    int w = (int)(pix % W), h = (int)((pix / W) % H), img = (int)(pix / ((size_t)W * H));
+    const N3dtDiv dc4 = n3dt_div(c4), dW = n3dt_div(W), dH = n3dt_div(H);
+    int cq = n3dt_rem(i, dc4);
+    size_t pix = n3dt_quot(i, dc4);
+    const size_t prow = n3dt_quot(pix, dW);
+    int w = n3dt_rem(pix, dW), h = n3dt_rem(prow, dH), img = (int)n3dt_quot(prow, dH);
     const float k[3] = {0.25f, 0.5f, 0.25f};
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -119,7 +121,8 @@ __global__ void to_rgb_kernel(int nb, int HW, int K, const float* __restrict__ n
             a2 = fmaf(wl[2 * K + k + j], v[j], a2);
         }
     }
-    size_t img = pix / HW, p = pix % HW;
+    const N3dtDiv dHW = n3dt_div(HW);
+    size_t img = n3dt_quot(pix, dHW), p = n3dt_rem(pix, dHW);
     size_t o = img * 3 * (size_t)HW + p;
     if (rgb_in) {
         a0 = rgb_in[o] + a0;
@@ -152,8 +155,10 @@ __global__ void rgb_up_kernel(int n_planes, int h, int w, const float* __restric
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int H2 = 2 * h, W2 = 2 * w;
     if (i >= (size_t)n_planes * H2 * W2) return;
-    int oj = (int)(i % W2), oi = (int)((i / W2) % H2);
-    size_t pl = i / ((size_t)W2 * H2);
+    const N3dtDiv dW2 = n3dt_div(W2), dH2 = n3dt_div(H2);
+    const size_t orow = n3dt_quot(i, dW2);
+    int oj = n3dt_rem(i, dW2), oi = n3dt_rem(orow, dH2);
+    size_t pl = n3dt_quot(orow, dH2);
     const float* xp = x + pl * (size_t)h * w;
     const float k[3] = {0.25f, 0.5f, 0.25f};
     float acc = 0.0f;

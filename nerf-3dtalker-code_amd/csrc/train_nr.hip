@@ -69,22 +69,26 @@ __global__ void nrt_shuffle_kernel(int nb, int H, int W, int C, const float* __r
     const size_t total = (size_t)nb * H * W * 4 * C;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int c = (int)(i % C);
-    size_t opix = i / C;  // output pixel
-    const int ow = (int)(opix % (2 * W)), oh = (int)((opix / (2 * W)) % (2 * H)), img = (int)(opix / ((size_t)4 * W * H));
+    const N3dtDiv dC = n3dt_div(C), dW2 = n3dt_div(2 * W), dH2 = n3dt_div(2 * H);
+    const int c = n3dt_rem(i, dC);
+    size_t opix = n3dt_quot(i, dC);  // output pixel
+    const size_t orow = n3dt_quot(opix, dW2);
+    const int ow = n3dt_rem(opix, dW2), oh = n3dt_rem(orow, dH2), img = (int)n3dt_quot(orow, dH2);
     const int h = oh >> 1, di = oh & 1, w = ow >> 1, dj = ow & 1;
     const size_t m = ((size_t)img * H + h) * W + w;
     const int o = 4 * c + 2 * di + dj;
-    ps[i] = tv[m * 4 * C + o] + x[m * C + (o % C)];
+    ps[i] = tv[m * 4 * C + o] + x[m * C + n3dt_rem(o, dC)];
 }
 
 __global__ void nrt_blur_kernel(int nb, int H, int W, int C, const float* __restrict__ x, float* __restrict__ y) {
     const int c4 = C / 4;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)nb * H * W * c4) return;
-    int cq = (int)(i % c4);
-    size_t pix = i / c4;
-    int w = (int)(pix % W), h = (int)((pix / W) % H), img = (int)(pix / ((size_t)W * H));
+    const N3dtDiv dc4 = n3dt_div(c4), dW = n3dt_div(W), dH = n3dt_div(H);
+    int cq = n3dt_rem(i, dc4);
+    size_t pix = n3dt_quot(i, dc4);
+    const size_t prow = n3dt_quot(pix, dW);
+    int w = n3dt_rem(pix, dW), h = n3dt_rem(prow, dH), img = (int)n3dt_quot(prow, dH);
     const float k[3] = {0.25f, 0.5f, 0.25f};
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -115,7 +119,8 @@ __global__ void nrt_to_rgb_kernel(int nb, int HW, int K, const float* __restrict
         a1 = fmaf(wl[K + k], v, a1);
         a2 = fmaf(wl[2 * K + k], v, a2);
     }
-    size_t img = pix / HW, p = pix % HW, o = img * 3 * (size_t)HW + p;
+    const N3dtDiv dHW = n3dt_div(HW);
+    size_t img = n3dt_quot(pix, dHW), p = n3dt_rem(pix, dHW), o = img * 3 * (size_t)HW + p;
     if (rgb_in) {
         a0 = rgb_in[o] + a0;
         a1 = rgb_in[o + HW] + a1;
@@ -144,8 +149,10 @@ __global__ void nrt_rgb_up_kernel(int n_planes, int h, int w, const float* __res
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int H2 = 2 * h, W2 = 2 * w;
     if (i >= (size_t)n_planes * H2 * W2) return;
-    int oj = (int)(i % W2), oi = (int)((i / W2) % H2);
-    size_t pl = i / ((size_t)W2 * H2);
+    const N3dtDiv dW2 = n3dt_div(W2), dH2 = n3dt_div(H2);
+    const size_t orow = n3dt_quot(i, dW2);
+    int oj = n3dt_rem(i, dW2), oi = n3dt_rem(orow, dH2);
+    size_t pl = n3dt_quot(orow, dH2);
     const float* xp = x + pl * (size_t)h * w;
     const float k[3] = {0.25f, 0.5f, 0.25f};
     float acc = 0.0f;
@@ -173,9 +180,11 @@ __global__ void nrt_blur_adj_kernel(int nb, int H, int W, int C, const float* __
     const int c4 = C / 4;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)nb * H * W * c4) return;
-    int cq = (int)(i % c4);
-    size_t pix = i / c4;
-    int w = (int)(pix % W), h = (int)((pix / W) % H), img = (int)(pix / ((size_t)W * H));
+    const N3dtDiv dc4 = n3dt_div(c4), dW = n3dt_div(W), dH = n3dt_div(H);
+    int cq = n3dt_rem(i, dc4);
+    size_t pix = n3dt_quot(i, dc4);
+    const size_t prow = n3dt_quot(pix, dW);
+    int w = n3dt_rem(pix, dW), h = n3dt_rem(prow, dH), img = (int)n3dt_quot(prow, dH);
     int ih[5], iw[5];
     float wh[5], ww[5];
     const int nh = blur_adj_taps(h, H, ih, wh), nw = blur_adj_taps(w, W, iw, ww);
@@ -192,8 +201,10 @@ __global__ void nrt_blur_adj_kernel(int nb, int H, int W, int C, const float* __
 __global__ void nrt_blur_adj_planar_kernel(int n_planes, int H, int W, const float* __restrict__ dy, float* __restrict__ dx) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n_planes * H * W) return;
-    int w = (int)(i % W), h = (int)((i / W) % H);
-    size_t pl = i / ((size_t)W * H);
+    const N3dtDiv dW = n3dt_div(W), dH = n3dt_div(H);
+    const size_t prow = n3dt_quot(i, dW);
+    int w = n3dt_rem(i, dW), h = n3dt_rem(prow, dH);
+    size_t pl = n3dt_quot(prow, dH);
     int ih[5], iw[5];
     float wh[5], ww[5];
     const int nh = blur_adj_taps(h, H, ih, wh), nw = blur_adj_taps(w, W, iw, ww);
@@ -217,8 +228,10 @@ __device__ __forceinline__ int bil_adj_taps(int m, int n, int idx[4], float wt[4
 __global__ void nrt_bilinear_adj_kernel(int n_planes, int h, int w, const float* __restrict__ dy /*[2h][2w]*/, float* __restrict__ dx) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n_planes * h * w) return;
-    int jw = (int)(i % w), jh = (int)((i / w) % h);
-    size_t pl = i / ((size_t)w * h);
+    const N3dtDiv dw = n3dt_div(w), dh = n3dt_div(h);
+    const size_t prow = n3dt_quot(i, dw);
+    int jw = n3dt_rem(i, dw), jh = n3dt_rem(prow, dh);
+    size_t pl = n3dt_quot(prow, dh);
     int ih[4], iw[4];
     float wh[4], ww[4];
     const int nh = bil_adj_taps(jh, h, ih, wh), nw = bil_adj_taps(jw, w, iw, ww);
@@ -244,8 +257,9 @@ __global__ void nrt_to_rgb_bwd_kernel(int nb, int HW, int K, const float* __rest
     const int k4 = K / 4;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)nb * HW * k4) return;
-    const int kq = (int)(i % k4);
-    const size_t pix = i / k4, img = pix / HW, p = pix % HW, o = img * 3 * (size_t)HW + p;
+    const N3dtDiv dk4 = n3dt_div(k4), dHW = n3dt_div(HW);
+    const int kq = n3dt_rem(i, dk4);
+    const size_t pix = n3dt_quot(i, dk4), img = n3dt_quot(pix, dHW), p = n3dt_rem(pix, dHW), o = img * 3 * (size_t)HW + p;
     const float d0 = d_rgb[o], d1 = d_rgb[o + HW], d2 = d_rgb[o + 2 * (size_t)HW];
     f32x4 v;
 #pragma unroll
@@ -272,9 +286,11 @@ __global__ void nrt_unshuffle_kernel(int nb, int H, int W, int C, const float* _
     const size_t total = (size_t)nb * H * W * C;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int cp = (int)(i % C);  // residual channel c' : receives every o with o % C == c'
-    const size_t m = i / C;
-    const int w = (int)(m % W), h = (int)((m / W) % H), img = (int)(m / ((size_t)W * H));
+    const N3dtDiv dC = n3dt_div(C), dW = n3dt_div(W), dH = n3dt_div(H);
+    const int cp = n3dt_rem(i, dC);  // residual channel c' : receives every o with o % C == c'
+    const size_t m = n3dt_quot(i, dC);
+    const size_t prow = n3dt_quot(m, dW);
+    const int w = n3dt_rem(m, dW), h = n3dt_rem(prow, dH), img = (int)n3dt_quot(prow, dH);
     float res = 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
