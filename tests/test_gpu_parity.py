@@ -3,7 +3,8 @@ the reference and against the CPU oracle.  Needs an MI355X: run with `-m gpu`.
 
 Tolerances (floating point, stated per BASELINE.json north_star):
   fp32 mode  : RGB L-inf <= 1e-3 is the gate; measured ~1e-5, asserted at 1e-4 to catch drift early.
-  bf16 / f16 : measured RGB L-inf 4e-4 / 8e-5 on the fixtures; asserted at 2e-3 / 5e-4.
+  bf16 / f16 : measured RGB L-inf <= 5.4e-4 / 9.2e-5 on the fixtures; asserted at 1e-3 (the north-star gate itself,
+               so the headline bf16 mode is held to it too) / 5e-4.
 """
 import numpy as np
 import pytest
@@ -13,7 +14,7 @@ from conftest import load_golden, synthetic_case, options_from_manifest
 
 pytestmark = pytest.mark.gpu
 
-RGB_TOL = {"fp32": 1e-4, "bf16": 2e-3, "fp16": 5e-4}
+RGB_TOL = {"fp32": 1e-4, "bf16": 1e-3, "fp16": 5e-4}
 FEAT_TOL = {"fp32": 2e-5, "bf16": 5e-3, "fp16": 1e-3}
 
 
