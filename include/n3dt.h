@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define N3DT_ABI_VERSION 1
+#define N3DT_ABI_VERSION 2
 
 /* arithmetic type of the MLP contraction */
 #define N3DT_F32 0  /* v_mfma_f32_16x16x4_f32, exact fp32: the <=1e-3 RGB parity mode */
@@ -59,6 +59,10 @@ typedef struct N3dtGeom {
     /* element strides of batch_xy [B,2,N_r]; the trainer passes an expand()ed view
      * (reference: talker_trainer.py:768), so stride_b may be 0 */
     int64_t xy_stride_b, xy_stride_c, xy_stride_r;
+    /* 0: the N_s+1 sample planes of a ray are the reference's linspace between world_z1 / world_z2 (jittered by
+     * `t_rand` in train mode, NetWorks/utils.py:118-145);  1: the `t_rand` argument of the render calls carries the
+     * planes themselves, [B,N_r,N_s+1] ascending camera-relative z (the hierarchical pass, utils.py:173-208) */
+    int32_t z_planes_given;
 } N3dtGeom;
 
 /* The MLP's fp32 parameters as PyTorch owns them: weight[l] is [out_l, in_l] row-major
@@ -119,7 +123,8 @@ int n3dt_mlp_pack(const N3dtGeom* g, int precision, const N3dtMlpParams* p, void
  * (HeadNeRFNet.py:103-112).
  *   xy      batch_xy, strides in g                R, Kinv [B,3,3]     T [B,3]
  *   shape [B,shape_dim]  appea [B,appea_dim]  audio [B,audio_dim] (NULL iff audio_dim==0)
- *   t_rand  [B,N_r,N_s+1] uniform noise for mode=="train" (utils.py:73-78), NULL for "test"
+ *   t_rand  [B,N_r,N_s+1] uniform noise for mode=="train" (utils.py:73-78), NULL for "test";
+ *           with g->z_planes_given: the sample planes themselves (see N3dtGeom)
  *   bg_featmap  neural_render.bg_featmap [C, N_r] (NCHW parameter), NULL to skip the merge
  * outputs (any may be NULL except fg_feat):
  *   fg_feat [B,N_r,C]  bg_alpha [B,N_r]  depth [B,N_r]  weight [B,N_r,N_s]
@@ -132,6 +137,20 @@ int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, co
                     const float* bg_featmap,
                     float* fg_feat, float* bg_alpha, float* depth, float* weight, float* merge_feat,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- hierarchical (fine) sample planes: SURVEY 8f row 4 ------------------------------------------
+ * Replaces FineSample.forward (NetWorks/utils.py:211-263): inverse-CDF resampling of the coarse pass.
+ *   g         geometry of the COARSE pass (n_samples = N_c >= 3); its z_planes_given must be 0
+ *   n_fine    opt.num_sample_fine (N_f); n_fine + 1 samples are drawn
+ *   weight    [B,N_r,N_c] compositing weights of the coarse pass (n3dt_render_fwd's `weight`)
+ *   T, t_rand as given to the coarse pass (the coarse planes are recomputed from them)
+ *   u         [B*N_r, N_f+1] uniform samples for mode=="train" (torch.rand at utils.py:227), NULL: linspace(0,1)
+ *   z_planes  [B,N_r,N_c+N_f+1] out, ascending: the coarse planes merged with the new ones (utils.py:248).
+ * The fine pass is then n3dt_render_fwd with n_samples = N_c + N_f, z_planes_given = 1, t_rand = z_planes and the
+ * fine network's parameters (the reference's own call site, HeadNeRFNet.py:182-185, omits two arguments and cannot
+ * run; this is that call with them supplied). */
+int n3dt_fine_sample(const N3dtGeom* g, int n_fine, const float* weight, const float* T, const float* t_rand, const float* u,
+                     float* z_planes, void* stream);
 
 /* ---- 2-D neural renderer: a8..a10 ----------------------------------------------------------------
  * Replaces NeuralRenderer.forward (NetWorks/neural_renderer.py:72-91) including

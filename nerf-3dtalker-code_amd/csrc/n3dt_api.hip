@@ -15,6 +15,7 @@ void n3dt_launch_fold(const N3dtGeom*, const N3dtMlpParams*, const float*, const
 void n3dt_launch_ray_head(const N3dtGeom*, int, int, const float*, const float*, const float*, const float*, float*, float*,
                           float*, float*, float*, hipStream_t);
 void n3dt_launch_chw_to_hwc(int, int, const float*, float*, hipStream_t);
+void n3dt_launch_fine_sample(const N3dtGeom*, int, const float*, const float*, const float*, const float*, float*, hipStream_t);
 void n3dt_launch_nerf_fwd_f32(const N3dtGeom*, const N3dtMlpParams*, const void*, const float*, const float*, const float*,
                               const float*, const float*, const float*, float*, float*, hipStream_t);
 void n3dt_launch_nerf_fwd_x16(const N3dtGeom*, int, const void*, const float*, const float*, const float*, const float*,
@@ -174,6 +175,7 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
         return fail(N3DT_EINVAL, "n3dt_render_fwd: NULL argument");
     if (g->audio_dim > 0 && !audio) return fail(N3DT_EINVAL, "n3dt_render_fwd: audio is NULL but audio_dim > 0");
     if (merge_feat && !bg_featmap) return fail(N3DT_EINVAL, "n3dt_render_fwd: merge_feat needs bg_featmap");
+    if (g->z_planes_given && !t_rand) return fail(N3DT_EINVAL, "n3dt_render_fwd: z_planes_given but no planes passed as t_rand");
     const RenderCarve c = render_carve(g, precision);
     if (workspace_bytes < c.total) return fail(N3DT_EWORKSPACE, "n3dt_render_fwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -198,6 +200,18 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
     const float* tail = (const float*)((const unsigned char*)packed_mlp + n3dt_packed_tail_offset(precision));
     n3dt_launch_ray_head(g, c.bpr, c.bs, part, wlocal, tail, bg_featmap, fg_feat, bg_alpha, depth, weight, merge_feat, s);
     return check_hip("n3dt_render_fwd");
+}
+
+extern "C" int n3dt_fine_sample(const N3dtGeom* g, int n_fine, const float* weight, const float* T, const float* t_rand, const float* u,
+                                float* z_planes, void* stream) {
+    int rc = check_geom(g, N3DT_F32);
+    if (rc) return rc;
+    if (!weight || !T || !z_planes) return fail(N3DT_EINVAL, "n3dt_fine_sample: NULL argument");
+    if (g->z_planes_given) return fail(N3DT_EINVAL, "n3dt_fine_sample: the coarse pass must use the built-in planes");
+    if (g->n_samples < 3) return fail(N3DT_EINVAL, "n3dt_fine_sample: needs at least 3 coarse samples");
+    if (n_fine < 0 || g->n_samples + n_fine + 1 > 2048) return fail(N3DT_EINVAL, "n3dt_fine_sample: more than 2048 planes per ray");
+    n3dt_launch_fine_sample(g, n_fine, weight, T, t_rand, u, z_planes, (hipStream_t)stream);
+    return check_hip("n3dt_fine_sample");
 }
 
 extern "C" size_t n3dt_neural_render_workspace_bytes(const N3dtGeom* g, int nb) {

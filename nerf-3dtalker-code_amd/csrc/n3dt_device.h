@@ -86,8 +86,14 @@ __device__ __forceinline__ void n3dt_sample_point(const N3dtGeom& g, const float
     const int Ns = g.n_samples;
     if (s < Ns) {
         const float* tr = t_rand ? t_rand + ((int64_t)b * g.n_rays + ray) * (Ns + 1) : nullptr;
-        float z_lo = n3dt_edge_z(rz1, rz2, s, Ns, tr);
-        float z_hi = n3dt_edge_z(rz1, rz2, s + 1, Ns, tr);
+        float z_lo, z_hi;
+        if (g.z_planes_given) {  // hierarchical pass: the planes come from n3dt_fine_sample (utils.py:173-183)
+            z_lo = tr[s];
+            z_hi = tr[s + 1];
+        } else {
+            z_lo = n3dt_edge_z(rz1, rz2, s, Ns, tr);
+            z_hi = n3dt_edge_z(rz1, rz2, s + 1, Ns, tr);
+        }
         dist = (z_hi - z_lo) * l;
         zval = z_lo;
 #pragma unroll

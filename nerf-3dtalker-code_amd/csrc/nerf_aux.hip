@@ -334,3 +334,85 @@ __global__ void chw_to_hwc_kernel(int C, int n, const float* __restrict__ src, f
 extern "C" void n3dt_launch_chw_to_hwc(int C, int n, const float* src, float* dst, hipStream_t stream) {
     hipLaunchKernelGGL(chw_to_hwc_kernel, dim3((n + 31) / 32, (C + 31) / 32), dim3(256), 0, stream, C, n, src, dst);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Hierarchical sample planes.  FineSample.forward, NetWorks/utils.py:211-254, one wave per ray:
+//   pdf over the interior coarse weights w[1 .. Nc-2] (+1e-5 in the normaliser only), cdf = [0, cumsum(pdf)]
+//   (Nc-1 entries), Nf+1 uniform samples u (linspace, or the caller's torch.rand in train mode),
+//   inds = searchsorted(cdf, u, right=True), below = max(0, inds-1), above = min(Nc-2, inds), bins = midpoints of
+//   the coarse planes, t = (u - cdf[below]) / (cdf[above] - cdf[below], 1 where < 1e-5),
+//   z = bins[below] + t (bins[above] - bins[below]);  all planes = sort(coarse planes ++ z).
+// The cumulative sum runs sequentially like torch.cumsum; the sort is a stable rank sort (<= 2 K elements per ray).
+// ---------------------------------------------------------------------------------------------
+#define FS_MAX_PLANES 2048
+__global__ __launch_bounds__(64) void fine_sample_kernel(N3dtGeom g, int n_fine, const float* __restrict__ weight,
+                                                         const float* __restrict__ T, const float* __restrict__ t_rand,
+                                                         const float* __restrict__ u_in, float* __restrict__ z_out) {
+    extern __shared__ float fs_lds[];
+    const int Nc = g.n_samples, Nu = n_fine + 1, Nall = Nc + Nu;
+    float* zc = fs_lds;           // [Nc] coarse planes (the first Nc of the Nc+1 edges, utils.py:83)
+    float* cdf = zc + Nc;         // [Nc - 1]
+    float* all = cdf + (Nc - 1);  // [Nall]
+    const long rayg = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int b = (int)(rayg / g.n_rays);
+    const float rz1 = T[b * 3 + 2] - g.world_z1, rz2 = T[b * 3 + 2] - g.world_z2;
+    const float* tr = t_rand ? t_rand + rayg * (Nc + 1) : nullptr;
+    const float* w = weight + rayg * Nc;
+    for (int j = lane; j < Nc; j += 64) {
+        const float z = n3dt_edge_z(rz1, rz2, j, Nc, tr);
+        zc[j] = z;
+        all[j] = z;
+    }
+    float part = 0.0f;
+    for (int j = 1 + lane; j < Nc - 1; j += 64) part += w[j] + 1e-5f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    const float total = part;
+    __syncthreads();
+    if (lane == 0) {
+        float run = 0.0f;
+        cdf[0] = 0.0f;
+        for (int j = 0; j < Nc - 2; ++j) {
+            run += w[j + 1] / total;
+            cdf[j + 1] = run;
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < Nu; i += 64) {
+        const float u = u_in ? u_in[rayg * Nu + i] : n3dt_linspace01(i, Nu);
+        int lo = 0, hi = Nc - 1;  // upper bound: number of cdf entries <= u
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1;
+            else hi = mid;
+        }
+        const int inds = lo;
+        const int below = inds - 1 > 0 ? inds - 1 : 0;
+        const int above = inds < Nc - 2 ? inds : Nc - 2;
+        const float c0 = cdf[below], c1 = cdf[above];
+        const float b0 = 0.5f * (zc[below + 1] + zc[below]), b1 = 0.5f * (zc[above + 1] + zc[above]);
+        float denom = c1 - c0;
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = (u - c0) / denom;
+        all[Nc + i] = b0 + t * (b1 - b0);
+    }
+    __syncthreads();
+    float* out = z_out + rayg * Nall;
+    for (int i = lane; i < Nall; i += 64) {
+        const float v = all[i];
+        int rank = 0;
+        for (int j = 0; j < Nall; ++j) {
+            const float o = all[j];
+            rank += (o < v || (o == v && j < i)) ? 1 : 0;
+        }
+        out[rank] = v;
+    }
+}
+
+extern "C" void n3dt_launch_fine_sample(const N3dtGeom* g, int n_fine, const float* weight, const float* T, const float* t_rand,
+                                        const float* u, float* z_planes, hipStream_t stream) {
+    const long rays = (long)g->batch * g->n_rays;
+    const size_t lds = sizeof(float) * ((size_t)g->n_samples * 2 - 1 + g->n_samples + n_fine + 1);
+    hipLaunchKernelGGL(fine_sample_kernel, dim3((unsigned)rays), dim3(64), lds, stream, *g, n_fine, weight, T, t_rand, u, z_planes);
+}

@@ -25,6 +25,7 @@ class Geom(ctypes.Structure):
         ("appea_dim", ctypes.c_int32), ("audio_dim", ctypes.c_int32), ("featmap_size", ctypes.c_int32),
         ("n_blocks", ctypes.c_int32), ("world_z1", ctypes.c_float), ("world_z2", ctypes.c_float),
         ("xy_stride_b", ctypes.c_int64), ("xy_stride_c", ctypes.c_int64), ("xy_stride_r", ctypes.c_int64),
+        ("z_planes_given", ctypes.c_int32),
     ]
 
 
@@ -47,7 +48,7 @@ EXPORTS = [
     "n3dt_neural_render_fwd", "n3dt_chw_to_hwc", "n3dt_prof_enable", "n3dt_prof_collect",
     "n3dt_render_train_saved_bytes", "n3dt_render_train_workspace_bytes", "n3dt_render_train_fwd", "n3dt_render_bwd",
     "n3dt_neural_render_train_saved_bytes", "n3dt_neural_render_train_workspace_bytes",
-    "n3dt_neural_render_train_fwd", "n3dt_neural_render_bwd", "n3dt_loss_fwd", "n3dt_loss_bwd",
+    "n3dt_neural_render_train_fwd", "n3dt_neural_render_bwd", "n3dt_loss_fwd", "n3dt_loss_bwd", "n3dt_fine_sample",
 ]
 
 _LIB = None
@@ -107,7 +108,9 @@ def lib():
     L.n3dt_prof_enable.argtypes = [ci]
     L.n3dt_prof_collect.restype = ci
     L.n3dt_prof_collect.argtypes = [ctypes.POINTER(ctypes.c_float), ci, ctypes.POINTER(ci)]
-    if L.n3dt_abi_version() != 1:
+    L.n3dt_fine_sample.restype = ci
+    L.n3dt_fine_sample.argtypes = [gp, ci, vp, vp, vp, vp, vp, vp]
+    if L.n3dt_abi_version() != 2:
         raise N3dtError("libn3dt.so ABI version mismatch")
     _LIB = L
     return L

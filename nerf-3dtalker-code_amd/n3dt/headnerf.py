@@ -248,9 +248,9 @@ class HeadNeRFNet(nn.Module):
     def __init__(self, opt, include_vd, hier_sampling, include_gaze=False, eye_gaze_dim=2, audio_dim=64, precision="fp32",
                  train_precision="fp32"):
         super().__init__()
-        if hier_sampling:
-            # the reference's fine branch raises TypeError at its call site (HeadNeRFNet.py:182-185)
-            raise NotImplementedError("hier_sampling=True is unreachable in the reference and not built here")
+        # hier_sampling=True: the reference builds FineSample + a second MLP (HeadNeRFNet.py:67-74) but its call site omits
+        # two arguments (:182-185) and raises TypeError; here the fine pass runs, with those arguments supplied
+        # (inference; the differentiable path covers the coarse network only)
         if include_vd:
             raise NotImplementedError("include_vd=True is never used by the reference's callers and not built here")
         self.hier_sampling = hier_sampling
@@ -288,6 +288,10 @@ class HeadNeRFNet(nn.Module):
         self.sample_func = _Seam("GenSamplePoints")
         self.fg_CD_predictor = MLPforNeRF(vp_channels=vp_channels, vd_channels=vd_channels, h_channel=self.mlp_h_channel,
                                           res_nfeat=self.featmap_nc, audio_dim=self.audio_dim)
+        if self.hier_sampling:
+            self.fine_samp_func = _Seam("FineSample")
+            self.fine_fg_CD_predictor = MLPforNeRF(vp_channels=vp_channels, vd_channels=vd_channels, h_channel=self.mlp_h_channel,
+                                                   res_nfeat=self.featmap_nc, audio_dim=self.audio_dim)
         self.calc_color_func = _Seam("CalcRayColor")
         self.neural_render = NeuralRenderer(bg_type=self.opt.bg_type, feat_nc=self.featmap_nc, out_dim=3, final_actvn=True,
                                             min_feat=32, featmap_size=self.featmap_size, img_size=self.pred_img_size)
@@ -296,20 +300,20 @@ class HeadNeRFNet(nn.Module):
     def _shape_dim(self):
         return self.base_shape_code_dims + (self.eye_gaze_dim if self.include_gaze else 0)
 
-    def _geom(self, batch, n_rays, xy):
-        return ops.make_geom(batch, n_rays, self.num_sample_coarse, self.mlp_h_channel, self.featmap_nc, self._shape_dim(),
-                             self.base_appea_code_dims, self.audio_dim, self.featmap_size, self.neural_render.n_blocks,
-                             self.opt.world_z1, self.opt.world_z2, xy.stride())
+    def _geom(self, batch, n_rays, xy, n_samples=None, z_planes_given=0):
+        return ops.make_geom(batch, n_rays, n_samples or self.num_sample_coarse, self.mlp_h_channel, self.featmap_nc,
+                             self._shape_dim(), self.base_appea_code_dims, self.audio_dim, self.featmap_size,
+                             self.neural_render.n_blocks, self.opt.world_z1, self.opt.world_z2, xy.stride(), z_planes_given)
 
-    def _mlp_params(self):
-        layers = self.fg_CD_predictor.layers()
+    def _mlp_params(self, fine=False):
+        layers = (self.fine_fg_CD_predictor if fine else self.fg_CD_predictor).layers()
         ws = [m.w2d().detach() for m in layers]
         bs = [m.bias.detach() for m in layers]
         return ops.mlp_params(ws, bs), ws, bs
 
     def _packed(self, geom, precision, params, ws, bs):
         """Packed weights, re-packed whenever the optimizer (or a load) touched a parameter."""
-        key = (precision, ws[0].device.index)
+        key = (precision, ws[0].device.index, ws[0].data_ptr())
         ver = tuple((t.data_ptr(), t._version) for t in ws + bs)
         hit = self._pack_cache.get(key)
         if hit is None or hit[0] != ver:
@@ -318,14 +322,21 @@ class HeadNeRFNet(nn.Module):
         return hit[1]
 
     def render_features(self, batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
-                        t_rand=None, want_depth=False, want_weight=False, want_merge=True, precision=None, merge_out=None):
-        """Rays -> composited feature map (seams a1..a7).  Outputs are ray-major [B, N_r, C]."""
+                        t_rand=None, want_depth=False, want_weight=False, want_merge=True, precision=None, merge_out=None,
+                        z_planes=None):
+        """Rays -> composited feature map (seams a1..a7).  Outputs are ray-major [B, N_r, C].
+        z_planes [B, N_r, N+1] (from fine_planes()): the hierarchical pass -- those planes, the fine network."""
         prec = _lib.PRECISIONS[precision or self.precision]
         B, tv, n_r = batch_xy.size()
         assert tv == 2
         xy = batch_xy if batch_xy.dtype == torch.float32 else batch_xy.float()
-        geom = self._geom(B, n_r, xy)
-        params, ws, bs = self._mlp_params()
+        if z_planes is not None:
+            assert self.hier_sampling and t_rand is None
+            t_rand = z_planes
+            geom = self._geom(B, n_r, xy, n_samples=z_planes.shape[-1] - 1, z_planes_given=1)
+        else:
+            geom = self._geom(B, n_r, xy)
+        params, ws, bs = self._mlp_params(fine=z_planes is not None)
         packed = self._packed(geom, prec, params, ws, bs)
         audio = ops._f32c(audiostyle) if self.audio_dim > 0 else None
         out = ops.render_fwd(geom, prec, packed, params, xy, ops._f32c(batch_Rmats), ops._f32c(batch_Tvecs).view(B, 3),
@@ -335,8 +346,16 @@ class HeadNeRFNet(nn.Module):
                              want_depth=want_depth, want_weight=want_weight, want_merge=want_merge, merge_out=merge_out)
         return out
 
+    def fine_planes(self, batch_xy, coarse_weight, batch_Tvecs, t_rand=None, fine_u=None):
+        """FineSample.forward (NetWorks/utils.py:211-263): coarse compositing weights [B, N_r, N_c] -> the
+        N_c + N_f + 1 ascending sample planes of the fine pass.  fine_u [B*N_r, N_f+1]: the uniform samples of train mode."""
+        B, _, n_r = batch_xy.size()
+        xy = batch_xy if batch_xy.dtype == torch.float32 else batch_xy.float()
+        return ops.fine_sample(self._geom(B, n_r, xy), self.num_sample_fine, ops._f32c(coarse_weight), ops._f32c(batch_Tvecs).view(B, 3),
+                               None if t_rand is None else ops._f32c(t_rand), None if fine_u is None else ops._f32c(fine_u))
+
     def _forward(self, for_train, batch_xy, batch_uv, audiostyle, bg_code, shape_code, appea_code, batch_Rmats,
-                 batch_Tvecs, batch_inv_inmats, dist_expr, t_rand=None):
+                 batch_Tvecs, batch_inv_inmats, dist_expr, t_rand=None, fine_u=None):
         batch_size, tv, n_r = batch_xy.size()
         assert tv == 2
         assert bg_code is None
@@ -351,15 +370,29 @@ class HeadNeRFNet(nn.Module):
             any(p.requires_grad for p in self.parameters()) or
             any(torch.is_tensor(t) and t.requires_grad for t in (audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs)))
         if needs_grad:
+            if self.hier_sampling:
+                raise NotImplementedError("the differentiable path covers the coarse network; run hier_sampling=True under torch.no_grad()")
             return self._forward_train(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand)
-        # the merged maps and the background map go through the 2-D renderer in one call (nb = B+1); the render
-        # kernel writes its merged maps straight into that batch
-        maps = torch.empty(batch_size + 1, fs, fs, C, dtype=torch.float32, device=batch_xy.device)
-        self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
-                             t_rand=t_rand, want_merge=True, merge_out=maps[:batch_size].view(batch_size, fs * fs, C))
-        ops.chw_to_hwc(self.neural_render.bg_featmap.detach().view(C, fs * fs), C, fs * fs, maps[batch_size].view(fs * fs, C))
+        # the merged maps (coarse, then fine) and the background map go through the 2-D renderer in one call; the
+        # render kernel writes its merged maps straight into that batch
+        n_pass = 2 if self.hier_sampling else 1
+        nb = n_pass * batch_size
+        maps = torch.empty(nb + 1, fs, fs, C, dtype=torch.float32, device=batch_xy.device)
+        coarse = self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
+                                      t_rand=t_rand, want_weight=self.hier_sampling, want_merge=True,
+                                      merge_out=maps[:batch_size].view(batch_size, fs * fs, C))
+        if self.hier_sampling:
+            if for_train and fine_u is None:  # the reference's torch.rand(num_temp, NFsample) (NetWorks/utils.py:227)
+                fine_u = torch.rand(batch_size * n_r, self.num_sample_fine + 1, device=batch_xy.device, dtype=torch.float32)
+            planes = self.fine_planes(batch_xy, coarse["weight"], batch_Tvecs, t_rand=t_rand, fine_u=fine_u)
+            self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
+                                 z_planes=planes, want_merge=True, merge_out=maps[batch_size:nb].view(batch_size, fs * fs, C))
+        ops.chw_to_hwc(self.neural_render.bg_featmap.detach().view(C, fs * fs), C, fs * fs, maps[nb].view(fs * fs, C))
         imgs = self.neural_render.render_hwc(maps, self.precision)
-        return {"coarse_dict": {"merge_img": imgs[:batch_size], "bg_img": imgs[batch_size:]}}
+        res = {"coarse_dict": {"merge_img": imgs[:batch_size], "bg_img": imgs[nb:]}}
+        if self.hier_sampling:
+            res["fine_dict"] = {"merge_img": imgs[batch_size:nb], "bg_img": imgs[nb:]}
+        return res
 
     def _forward_train(self, batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand):
         """Differentiable forward (exact fp32): gradients reach every parameter, audiostyle, shape_code, appea_code and
@@ -382,4 +415,5 @@ class HeadNeRFNet(nn.Module):
                 batch_Rmats=None, batch_Tvecs=None, batch_inv_inmats=None, dist_expr=False, **kwargs):
         assert mode in ["train", "test"]
         return self._forward(mode == "train", batch_xy, batch_uv, audiostyle, bg_code, shape_code, appea_code,
-                             batch_Rmats, batch_Tvecs, batch_inv_inmats, dist_expr, t_rand=kwargs.get("t_rand"))
+                             batch_Rmats, batch_Tvecs, batch_inv_inmats, dist_expr, t_rand=kwargs.get("t_rand"),
+                             fine_u=kwargs.get("fine_u"))

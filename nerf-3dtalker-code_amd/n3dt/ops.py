@@ -47,8 +47,9 @@ WORKSPACE = _Workspace()
 
 
 def make_geom(batch, n_rays, n_samples, hidden, feat_nc, shape_dim, appea_dim, audio_dim, featmap_size, n_blocks,
-              world_z1, world_z2, xy_strides=(0, 0, 0)):
+              world_z1, world_z2, xy_strides=(0, 0, 0), z_planes_given=0):
     g = Geom()
+    g.z_planes_given = int(z_planes_given)
     g.batch, g.n_rays, g.n_samples = int(batch), int(n_rays), int(n_samples)
     g.hidden, g.feat_nc = int(hidden), int(feat_nc)
     g.shape_dim, g.appea_dim, g.audio_dim = int(shape_dim), int(appea_dim), int(audio_dim)
@@ -116,6 +117,15 @@ def render_fwd(geom, precision, packed, params, xy, R, T, Kinv, shape, appea, au
         _ptr(ws), ws_bytes, _stream())
     check(rc, "n3dt_render_fwd")
     return out
+
+
+def fine_sample(geom, n_fine, weight, T, t_rand=None, u=None):
+    """Hierarchical sample planes (FineSample.forward): coarse weights [B,Nr,Nc] -> planes [B,Nr,Nc+n_fine+1]."""
+    B, Nr, Nc = geom.batch, geom.n_rays, geom.n_samples
+    z = torch.empty(B, Nr, Nc + n_fine + 1, dtype=torch.float32, device=weight.device)
+    check(lib().n3dt_fine_sample(ctypes.byref(geom), int(n_fine), _ptr(weight), _ptr(T), _ptr(t_rand), _ptr(u), _ptr(z), _stream()),
+          "n3dt_fine_sample")
+    return z
 
 
 def neural_render_fwd(geom, nb, rparams, featmap, precision=0):

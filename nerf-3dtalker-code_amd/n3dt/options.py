@@ -34,6 +34,8 @@ class BaseOptions(object):
         # synthetic configs can vary the per-ray sample count
         if "num_sample_coarse" in para_dict:
             self.num_sample_coarse = para_dict["num_sample_coarse"]
+        if "num_sample_fine" in para_dict:
+            self.num_sample_fine = para_dict["num_sample_fine"]
 
     def para(self):
         """The checkpoint `para` dict (reference: talker_trainer.py:915-936)."""

@@ -47,7 +47,7 @@ def mlp_dims(opt, include_gaze=False, eye_gaze_dim=2, audio_dim=64):
     }
 
 
-def param_specs(opt, include_gaze=False, eye_gaze_dim=2, audio_dim=64):
+def param_specs(opt, include_gaze=False, eye_gaze_dim=2, audio_dim=64, hier_sampling=False):
     """Ordered name -> (shape, init_kind, is_buffer).
 
     init_kind: "xavier" | "default_w" | "default_b" | "zero" | "ones" | "blur"
@@ -85,6 +85,17 @@ def param_specs(opt, include_gaze=False, eye_gaze_dim=2, audio_dim=64):
         conv(q + "feat_2_rgb_list.%d" % (i + 1), max(C // (2 ** (i + 1)), 32), 3, "default_w")
     for i in range(nb):
         conv(q + "feat_layers.%d" % i, max(C // (2 ** i), 32), max(C // (2 ** (i + 1)), 32), "default_w")
+    if hier_sampling:
+        # the second network of the hierarchical pass (NetWorks/HeadNeRFNet.py:72-74).  Listed last so that the seeded
+        # values of every other tensor do not depend on this flag.
+        p = "fine_fg_CD_predictor."
+        conv(p + "FeaExt_module_0", d["in0"], H, "default_w")
+        for i in range(1, 8):
+            conv(p + "FeaExt_module_%d" % i, d["in5"] if i == 5 else H, H, "xavier")
+        conv(p + "density_module", H, 1, "xavier", "zero")
+        conv(p + "RGB_layer_0", H, H, "xavier")
+        conv(p + "RGB_layer_1", d["in_rgb1"], H // 2, "default_w")
+        conv(p + "RGB_layer_2", H // 2, C, "default_w")
     return specs
 
 
@@ -108,7 +119,7 @@ def init_tensor(shape, kind, gen, fan_in_of_weight=None):
     return (torch.rand(shape, generator=gen) * 2.0 - 1.0) * a
 
 
-def make_state_dict(opt, seed=0, include_gaze=False, eye_gaze_dim=2, audio_dim=64, bg_noise=0.0):
+def make_state_dict(opt, seed=0, include_gaze=False, eye_gaze_dim=2, audio_dim=64, bg_noise=0.0, hier_sampling=False):
     """Seeded random weights with the reference's per-layer init distributions.
 
     bg_noise > 0 perturbs the learned background feature map away from its
@@ -117,13 +128,21 @@ def make_state_dict(opt, seed=0, include_gaze=False, eye_gaze_dim=2, audio_dim=6
     gen = torch.Generator().manual_seed(seed)
     sd = OrderedDict()
     last_fan_in = None
-    for name, (shape, kind, _buf) in param_specs(opt, include_gaze, eye_gaze_dim, audio_dim).items():
+    fine = OrderedDict()
+    for name, (shape, kind, _buf) in param_specs(opt, include_gaze, eye_gaze_dim, audio_dim, hier_sampling).items():
+        if name.startswith("fine_"):
+            fine[name] = (shape, kind)
+            continue
         if name.endswith(".weight"):
             last_fan_in = shape[1]
         sd[name] = init_tensor(shape, kind, gen, last_fan_in)
     if bg_noise > 0.0:
         k = "neural_render.bg_featmap"
         sd[k] = sd[k] + bg_noise * torch.randn(sd[k].shape, generator=gen)
+    for name, (shape, kind) in fine.items():  # drawn after everything else (see param_specs)
+        if name.endswith(".weight"):
+            last_fan_in = shape[1]
+        sd[name] = init_tensor(shape, kind, gen, last_fan_in)
     return sd
 
 

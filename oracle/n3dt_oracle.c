@@ -115,6 +115,66 @@ void orc_sample(int B, int Nr, int Ns, const float* xy, const float* R, const fl
 }
 
 /* ---------------------------------------------------------------------------------------
+ * f4: FineSample.forward                  NetWorks/utils.py:211-263 (hierarchical sample planes)
+ * weight [R][Nc] (coarse compositing weights), zc [R][Nc] (coarse zvals), u [R][Nf+1] or NULL (linspace),
+ * out [R][Nc+Nf+1] ascending.
+ * ------------------------------------------------------------------------------------- */
+static int cmp_float(const void* a, const void* b) {
+    float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+void orc_fine_sample(long R, int Nc, int Nf, const float* weight, const float* zc, const float* u_in, float* out) {
+    const int Nu = Nf + 1, Nt = Nc - 2, Nall = Nc + Nu;     /* utils.py:214,220 */
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < R; ++r) {
+        const float* w = weight + r * Nc + 1;               /* batch_weight[..., 1:-1]  (:219) */
+        const float* z = zc + r * Nc;
+        float* cdf = (float*)malloc(sizeof(float) * (Nt + 1));
+        float* o = out + r * Nall;
+        float total = 0.0f;
+        for (int j = 0; j < Nt; ++j) total += w[j] + 1e-5f;  /* x = w + 1e-5; sum(x)      (:223-224) */
+        cdf[0] = 0.0f;                                       /* F.pad(cdf, [1,0])         (:226) */
+        float run = 0.0f;
+        for (int j = 0; j < Nt; ++j) { run += w[j] / total; cdf[j + 1] = run; }   /* pdf, cumsum (:224-225) */
+        for (int j = 0; j < Nc; ++j) o[j] = z[j];
+        for (int i = 0; i < Nu; ++i) {
+            float u = u_in ? u_in[r * Nu + i] : linspace01(i, Nu);                /* :229-232 */
+            int inds = 0;                                                          /* searchsorted(right=True) (:235) */
+            while (inds < Nt + 1 && cdf[inds] <= u) ++inds;
+            int below = inds - 1 > 0 ? inds - 1 : 0;                               /* :236 */
+            int above = inds < Nt ? inds : Nt;                                     /* :237 */
+            float b0 = 0.5f * (z[below + 1] + z[below]), b1 = 0.5f * (z[above + 1] + z[above]);  /* bins (:241) */
+            float denom = cdf[above] - cdf[below];                                 /* :246 */
+            if (denom < 1e-5f) denom = 1.0f;                                       /* :247 */
+            float t = (u - cdf[below]) / denom;                                    /* :248 */
+            o[Nc + i] = b0 + t * (b1 - b0);                                        /* :249 */
+        }
+        qsort(o, (size_t)Nall, sizeof(float), cmp_float);                          /* torch.sort (:251) */
+        free(cdf);
+    }
+}
+
+/* FineSample._calc_sample_points_by_zvals  utils.py:173-208: planes [B][Nr][N+1] -> pts, zvals, z_dists over N samples */
+void orc_sample_planes(int B, int Nr, int N, const float* xy, const float* R, const float* T, const float* Kinv,
+                       const float* planes, float* pts, float* zvals, float* z_dists) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int r = 0; r < Nr; ++r) {
+            float d[3], l;
+            const float* Tb = T + b * 3;
+            ray_setup(R + b * 9, Tb, Kinv + b * 9, xy[(b * 2 + 0) * Nr + r], xy[(b * 2 + 1) * Nr + r], d, &l);
+            const float* z = planes + ((size_t)b * Nr + r) * (N + 1);
+            for (int s = 0; s < N; ++s) {
+                size_t o = ((size_t)b * Nr + r) * N + s;
+                if (z_dists) z_dists[o] = (z[s + 1] - z[s]) * l;   /* :182-183 */
+                if (zvals) zvals[o] = z[s];                        /* :185 */
+                if (pts)
+                    for (int i = 0; i < 3; ++i) pts[(((size_t)b * 3 + i) * Nr + r) * N + s] = Tb[i] + (d[i] * l) * z[s];  /* :188 */
+            }
+        }
+}
+
+/* ---------------------------------------------------------------------------------------
  * a3: Embedder.forward                    NetWorks/utils.py:20-51  (freqs 2^k, no pi)
  * pts [B,3,M] -> pe [B,63,M]: [p, sin(2^0 p), cos(2^0 p), ..., sin(2^9 p), cos(2^9 p)]
  * ------------------------------------------------------------------------------------- */

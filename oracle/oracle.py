@@ -91,6 +91,28 @@ def sample(xy, R, T, Kinv, n_samples, world_z1=2.5, world_z2=-3.5, t_rand=None):
     return {"ray_d": ray_d, "ray_l": ray_l, "pts": pts, "zvals": zvals, "z_dists": z_dists}
 
 
+def fine_sample(weight, zvals, n_fine, u=None):
+    """FineSample.forward: weight / zvals [B,1,Nr,Nc] (coarse) -> planes [B,Nr,Nc+n_fine+1]."""
+    weight, zvals = _f32(weight), _f32(zvals)
+    B, _, Nr, Nc = weight.shape
+    uu = _f32(u) if u is not None else None
+    out = np.empty((B, Nr, Nc + n_fine + 1), np.float32)
+    lib().orc_fine_sample(ctypes.c_long(B * Nr), Nc, int(n_fine), _p(weight), _p(zvals), _p(uu), _p(out))
+    return out
+
+
+def sample_planes(xy, R, T, Kinv, planes):
+    """FineSample._calc_sample_points_by_zvals: planes [B,Nr,N+1] -> pts / zvals / z_dists over N samples."""
+    xy, R, T, Kinv, planes = _f32(xy), _f32(R), _f32(T).reshape(-1, 3), _f32(Kinv), _f32(planes)
+    B, _, Nr = xy.shape
+    N = planes.shape[-1] - 1
+    pts = np.empty((B, 3, Nr, N), np.float32)
+    zvals = np.empty((B, 1, Nr, N), np.float32)
+    z_dists = np.empty((B, 1, Nr, N), np.float32)
+    lib().orc_sample_planes(B, Nr, N, _p(xy), _p(R), _p(T), _p(Kinv), _p(planes), _p(pts), _p(zvals), _p(z_dists))
+    return {"pts": pts, "zvals": zvals, "z_dists": z_dists}
+
+
 def embed(pts):
     pts = _f32(pts)
     B = pts.shape[0]
@@ -100,12 +122,12 @@ def embed(pts):
     return pe
 
 
-def mlp(sd, pe, shape, appea, audio, C=256, H=384):
+def mlp(sd, pe, shape, appea, audio, C=256, H=384, prefix="fg_CD_predictor."):
     pe, shape, appea = _f32(pe), _f32(shape), _f32(appea)
     audio = _f32(audio) if audio is not None and np.asarray(audio).size else None
     B = pe.shape[0]
     M = int(np.prod(pe.shape[2:]))
-    wl, keep = _ptr_array(mlp_weight_list(sd))
+    wl, keep = _ptr_array(mlp_weight_list(sd, prefix))
     rgb = np.empty((B, C) + pe.shape[2:], np.float32)
     dens = np.empty((B, 1) + pe.shape[2:], np.float32)
     lib().orc_mlp(B, ctypes.c_long(M), H, C, shape.shape[1], appea.shape[1], 0 if audio is None else audio.shape[1], wl,
@@ -172,3 +194,29 @@ def forward(sd, opt, inp, t_rand=None, skip_neural_render=False):
                       ctypes.c_float(opt.world_z1), ctypes.c_float(opt.world_z2), _p(tr), _p(shape), _p(appea), _p(audio),
                       _p(fg), _p(ba), _p(merge_img), _p(bg_img), int(skip_neural_render))
     return {"fg_feat": fg, "bg_alpha": ba, "merge_img": merge_img, "bg_img": bg_img}
+
+
+def forward_hier(sd, opt, inp, t_rand=None, fine_u=None):
+    """Coarse pass + hierarchical pass (HeadNeRFNet._forward with hier_sampling=True, the call at HeadNeRFNet.py:182-185
+    completed with its two missing arguments).  Returns the fine planes and both passes' composited features / images."""
+    import math
+    xy = _f32(_np(inp["batch_xy"]))
+    B, _, Nr = xy.shape
+    fs, C = opt.featmap_size, opt.featmap_nc
+    nb = int(math.log2(opt.pred_img_size) - math.log2(fs))
+    shape, appea = _np(inp["shape_code"]), _np(inp["appea_code"])
+    audio = _np(inp["audiostyle"]) if inp.get("audiostyle") is not None else None
+    R, T, K = _np(inp["batch_Rmats"]), _np(inp["batch_Tvecs"]), _np(inp["batch_inv_inmats"])
+    s = sample(xy, R, T, K, opt.num_sample_coarse, opt.world_z1, opt.world_z2, None if t_rand is None else _np(t_rand))
+    rgb, dens = mlp(sd, embed(s["pts"]), shape, appea, audio, C, opt.mlp_hidden_nchannels)
+    cfg, cba, _, cw = composite(rgb, dens, s["z_dists"], s["zvals"])
+    planes = fine_sample(cw, s["zvals"], opt.num_sample_fine, None if fine_u is None else _np(fine_u))
+    f = sample_planes(xy, R, T, K, planes)
+    rgb, dens = mlp(sd, embed(f["pts"]), shape, appea, audio, C, opt.mlp_hidden_nchannels, prefix="fine_fg_CD_predictor.")
+    ffg, fba, _, fw = composite(rgb, dens, f["z_dists"], f["zvals"])
+    bg = _f32(_np(sd["neural_render.bg_featmap"]))
+    out = {"planes": planes, "coarse_weight": cw, "coarse_fg": cfg, "fine_fg": ffg, "fine_bg_alpha": fba, "fine_weight": fw}
+    for name, fg, ba in (("coarse", cfg, cba), ("fine", ffg, fba)):
+        merge = fg.reshape(B, C, fs, fs) + ba.reshape(B, 1, fs, fs) * bg
+        out[name + "_merge_img"] = neural_render(sd, merge, nb)
+    return out

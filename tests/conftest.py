@@ -30,15 +30,19 @@ def golden():
 
 def options_from_manifest(m):
     from n3dt.options import BaseOptions
-    return BaseOptions({"featmap_size": m["featmap_size"], "featmap_nc": m["featmap_nc"],
-                        "pred_img_size": m["pred_img_size"], "num_sample_coarse": m["num_sample_coarse"]})
+    d = {"featmap_size": m["featmap_size"], "featmap_nc": m["featmap_nc"],
+         "pred_img_size": m["pred_img_size"], "num_sample_coarse": m["num_sample_coarse"]}
+    if "num_sample_fine" in m:
+        d["num_sample_fine"] = m["num_sample_fine"]
+    return BaseOptions(d)
 
 
 def synthetic_case(m, **kw):
     """Rebuild (opt, state_dict, inputs) of a fixture from its manifest and verify the weight checksum."""
     from n3dt import synthetic as syn
     opt = options_from_manifest(m)
-    sd = syn.make_state_dict(opt, seed=m.get("weights_seed", 0), bg_noise=m.get("bg_noise", 0.0), **kw)
+    sd = syn.make_state_dict(opt, seed=m.get("weights_seed", 0), bg_noise=m.get("bg_noise", 0.0),
+                             hier_sampling=bool(m.get("hier_sampling", False)), **kw)
     cs = syn.state_dict_checksum(sd)
     ref = m.get("weights_checksum")
     if ref is not None and not kw:

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), "libn3dt.so does not export %s" % name
-    assert L.n3dt_abi_version() == 1
+    assert L.n3dt_abi_version() == 2
 
 
 def test_geometry_validation_without_a_gpu():
@@ -69,8 +69,12 @@ def test_constructor_variants_and_rejections():
     assert g.state_dict()["fg_CD_predictor.FeaExt_module_0.weight"].shape[1] == 63 + 179 + 64 + 64
     y = HeadNeRFNet(opt, False, False, audio_dim=0)  # the *_yuan variant
     assert y.state_dict()["fg_CD_predictor.FeaExt_module_0.weight"].shape[1] == 242
+    h = HeadNeRFNet(opt, False, True)  # hier_sampling: the reference builds a second network (HeadNeRFNet.py:72-74)
+    from n3dt import synthetic as syn
+    assert set(h.state_dict().keys()) == set(syn.param_specs(opt, hier_sampling=True).keys())
+    assert h.state_dict()["fine_fg_CD_predictor.RGB_layer_1.weight"].shape == (192, 511, 1, 1)
     with pytest.raises(NotImplementedError):
-        HeadNeRFNet(opt, False, True)  # hier_sampling: broken in the reference
+        HeadNeRFNet(opt, True, False)  # include_vd: never used by the reference's callers
     opt.bg_type = "green"
     with pytest.raises(ValueError):
         HeadNeRFNet(opt, False, False)

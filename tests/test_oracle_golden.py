@@ -129,3 +129,31 @@ def test_forward_cfg1():
     assert np.abs(out["merge_img"] - ref).max() <= 1e-3
     refbg = g["bg_img_q16"].astype(np.float32) / 65535.0
     assert np.abs(out["bg_img"] - refbg).max() <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["hier_test", "hier_train"])
+def test_hierarchical_pass(name):
+    """FineSample (NetWorks/utils.py:211-263) and the fine pass, against vectors produced by driving the
+    reference's own modules in the order of HeadNeRFNet._forward (its call site itself cannot run).
+    The fine planes come from an inverse CDF of the coarse weights: isolated first (fed with the reference's weights),
+    then end to end (own weights; a plane can move by the weight error divided by a small pdf, hence the wider band)."""
+    from n3dt import synthetic as syn
+    g, m = load_golden(name)
+    opt, sd, inp = synthetic_case(m)
+    B, n_r = m["batch"], opt.featmap_size ** 2
+    t_rand = fine_u = None
+    if m["mode"] == "train":
+        t_rand = t2n(syn.stratified_noise(B, n_r, opt.num_sample_coarse, m["t_rand_seed"]))
+        fine_u = g["fine_u"]
+    planes = orc.fine_sample(g["coarse_weight"], g["coarse_zvals"], opt.num_sample_fine, fine_u)
+    np.testing.assert_allclose(planes[:, :, :-1], g["fine_zvals"][:, 0], atol=2e-5)
+    f = orc.sample_planes(t2n(inp["batch_xy"]), t2n(inp["batch_Rmats"]), t2n(inp["batch_Tvecs"]), t2n(inp["batch_inv_inmats"]), planes)
+    np.testing.assert_allclose(f["z_dists"], g["fine_z_dists"], atol=2e-5)
+    np.testing.assert_allclose(f["pts"][:, :, :1], g["fine_pts_ray0"], atol=2e-5)
+    out = orc.forward_hier(sd, opt, inp, t_rand=t_rand, fine_u=fine_u)
+    np.testing.assert_allclose(out["coarse_weight"], g["coarse_weight"], atol=2e-5)
+    assert np.abs(out["planes"][:, :, :-1] - g["fine_zvals"][:, 0]).max() <= 2e-3
+    np.testing.assert_allclose(out["fine_fg"], g["fine_fg_feat"], atol=5e-4)
+    np.testing.assert_allclose(out["fine_bg_alpha"], g["fine_bg_alpha"], atol=5e-4)
+    assert np.abs(out["coarse_merge_img"] - g["coarse_merge_img_q16"].astype(np.float32) / 65535.0).max() <= 1e-4
+    assert np.abs(out["fine_merge_img"] - g["fine_merge_img_q16"].astype(np.float32) / 65535.0).max() <= 1e-3

@@ -342,6 +342,57 @@ def gen_nr(HeadNeRFNet):
         "weights_seed": 0, "bg_noise": 0.1, "input_seed": 11, "weights_checksum": syn.state_dict_checksum(sd)}))
 
 
+def gen_hier(HeadNeRFNet, name, fs, nc, nf, pred, B, mode):
+    """Hierarchical pass.  The reference's own _forward cannot run with hier_sampling=True (its call
+    at HeadNeRFNet.py:182-185 omits `audiostyle` and `fg_vps`), so the same sequence of the reference's
+    modules is driven from here with those two arguments supplied."""
+    opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": pred, "num_sample_coarse": nc,
+                       "num_sample_fine": nf})
+    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1, hier_sampling=True)
+    net = HeadNeRFNet(opt, include_vd=False, hier_sampling=True)
+    net.load_state_dict(sd, strict=True)
+    inp = syn.frame_inputs(opt, B, yaw_range=0.3)
+    n_r, N = fs * fs, nc + nf
+    for_train = mode == "train"
+    t_rand = syn.stratified_noise(B, n_r, nc, 7) if for_train else None
+    fine_u = torch.rand(B * n_r, nf + 1, generator=torch.Generator().manual_seed(11)) if for_train else None
+    orig_rand_like, orig_rand = torch.rand_like, torch.rand
+    if for_train:
+        torch.rand_like = lambda z, *a, **k: t_rand.to(z)
+        torch.rand = lambda *a, **k: fine_u.clone()
+    colors = []
+    hook = net.calc_color_func.register_forward_hook(lambda _m, _i, o: colors.append(o))
+    try:
+        with torch.no_grad():
+            fg = net.sample_func(inp["batch_xy"], inp["batch_Rmats"], inp["batch_Tvecs"], inp["batch_inv_inmats"], for_train)
+
+            def ex(code, n):
+                return code.unsqueeze(-1).unsqueeze(-1).expand(-1, -1, n_r, n)
+            pe = net.vp_encoder(fg["pts"])
+            c_res, w = net.calc_color_with_code(ex(inp["audiostyle"], nc), fg["pts"], ex(inp["shape_code"], nc),
+                                                ex(inp["appea_code"], nc), pe, None, fg["z_dists"], fg["zvals"], fine_level=False)
+            fine = net.fine_samp_func(w, fg, for_train)
+            fpe = net.vp_encoder(fine["pts"])
+            f_res, fw = net.calc_color_with_code(ex(inp["audiostyle"], N), fine["pts"], ex(inp["shape_code"], N),
+                                                 ex(inp["appea_code"], N), fpe, None, fine["z_dists"], fine["zvals"], fine_level=True)
+    finally:
+        hook.remove()
+        torch.rand_like, torch.rand = orig_rand_like, orig_rand
+    arrays = {
+        "coarse_weight": np32(w), "coarse_zvals": np32(fg["zvals"]),
+        "fine_zvals": np32(fine["zvals"]), "fine_z_dists": np32(fine["z_dists"]), "fine_pts_ray0": np32(fine["pts"][:, :, :1]),
+        "fine_fg_feat": np32(colors[1][0]), "fine_bg_alpha": np32(colors[1][1]), "fine_weight": np32(fw),
+        "coarse_merge_img_q16": q16(np32(c_res["merge_img"])), "fine_merge_img_q16": q16(np32(f_res["merge_img"])),
+    }
+    if for_train:
+        arrays["fine_u"] = np32(fine_u)
+    save(name, arrays, manifest_base(name, opt, {
+        "batch": B, "mode": mode, "weights_seed": 0, "bg_noise": 0.1, "yaw_range": 0.3, "hier_sampling": True,
+        "num_sample_fine": nf, "t_rand_seed": 7, "fine_u_seed": 11,
+        "weights_checksum": syn.state_dict_checksum(sd),
+    }))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -357,6 +408,8 @@ def main():
         "cfg1": lambda: gen_cfg(HeadNeRFNet, "cfg1", fs=32, ns=32, pred=256, ray_step=16),
         "cfg2r": lambda: gen_cfg(HeadNeRFNet, "cfg2r", fs=64, ns=64, pred=512, ray_step=64),
         "hr": lambda: gen_cfg(HeadNeRFNet, "hr", fs=32, ns=96, pred=1024, ray_step=16, crop=256),
+        "hier_test": lambda: gen_hier(HeadNeRFNet, "hier_test", fs=8, nc=64, nf=128, pred=32, B=1, mode="test"),
+        "hier_train": lambda: gen_hier(HeadNeRFNet, "hier_train", fs=8, nc=16, nf=24, pred=32, B=2, mode="train"),
     }
     for k, fn in jobs.items():
         if args.only is None or k in args.only:
