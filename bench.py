@@ -80,11 +80,14 @@ def bench_train(args, net, opt, d, dev, world, rank):
     elapsed = float(t.item())
     if rank == 0:
         print(json.dumps({
-            "metric": "trained frames/sec @512^2 x 64 samples/ray (fwd+bwd+Adam)", "value": world * B * args.steps / elapsed,
+            "metric": "trained frames/sec @%d^2 x %d samples/ray (fwd+bwd+Adam)" % (opt.pred_img_size, opt.num_sample_coarse),
+            "value": world * B * args.steps / elapsed,
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": tp, "data": "synthetic",
-            "config": {"workload": "cfg3: %d heads/GPU/step, 64x64 rays x 64 samples -> 512x512, 3 MSE terms, Adam" % B,
+            "config": {"workload": "%s: %d heads/GPU/step, %dx%d rays x %d samples -> %dx%d, 3 MSE terms, Adam" % (
+                "cfg3" if args.config == "cfg2" else args.config + "-train", B, opt.featmap_size, opt.featmap_size,
+                opt.num_sample_coarse, opt.pred_img_size, opt.pred_img_size),
                        "parallelism": "frames sharded over %d rank(s), one flat gradient all-reduce per step" % world},
         }), flush=True)
 
@@ -100,8 +103,15 @@ def main():
                     help="R: rays = featmap_size^2 (reference-faithful); N: 512^2 rays, feature stage only")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render: forward-only (BASELINE config 2, the headline); train: fwd+loss+bwd+Adam (config 3, fp32)")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
+                    help="BASELINE.json geometry: cfg2 (headline: 64x64 rays x 64 samples -> 512^2; cfg3 with --mode train), "
+                         "cfg4 (32x32 rays x 64 samples -> 256^2, 4 heads per GPU), cfg5 (HR: 32x32 rays x 96 samples -> 1024^2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.config != "cfg2":
+        args.no_cpu_baseline = True  # the reported CPU baseline is the headline workload's
+        if args.batch == 8:
+            args.batch = 4
 
     import numpy as np
     import torch
@@ -128,7 +138,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    fs, ns, pred = 64, 64, 512
+    fs, ns, pred = {"cfg2": (64, 64, 512), "cfg4": (32, 64, 256), "cfg5": (32, 96, 1024)}[args.config]
     opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": pred, "num_sample_coarse": ns})
     sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
     net = HeadNeRFNet(opt, include_vd=False, hier_sampling=False, precision=args.precision).to(dev)
@@ -188,7 +198,7 @@ def main():
             with open(tpath) as f:
                 traffic = json.load(f).get("%s_%s_b%d" % (args.rays, args.precision, B))
         res = {
-            "metric": "rendered frames/sec @512^2 x 64 samples/ray",
+            "metric": "rendered frames/sec @%d^2 x %d samples/ray" % (pred, ns),
             "value": frames / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
@@ -201,9 +211,9 @@ def main():
             "dtype": args.precision,
             "data": "synthetic",
             "config": {
-                "workload": ("cfg2-R: %d heads/GPU/step, 64x64 rays x 64 samples -> fused MLP+composite -> neural renderer "
-                             "-> 512x512 RGB (+ background image)" % B) if args.rays == "R" else
-                            ("cfg2-N: %d heads/GPU/step, 512x512 rays x 64 samples, feature stage only" % B),
+                "workload": ("%s-R: %d heads/GPU/step, %dx%d rays x %d samples -> fused MLP+composite -> neural renderer "
+                             "-> %dx%d RGB (+ background image)" % (args.config, B, fs, fs, ns, pred, pred)) if args.rays == "R" else
+                            ("%s-N: %d heads/GPU/step, 512x512 rays x %d samples, feature stage only" % (args.config, B, ns)),
                 "frames_per_gpu_per_step": B, "rays_per_frame": n_rays, "samples_per_ray": ns,
                 "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
             },
