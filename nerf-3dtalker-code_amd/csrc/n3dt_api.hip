@@ -37,8 +37,8 @@ void n3dt_launch_train16_fwd(const N3dtGeom*, const N3dtMlpParams*, const void*,
                              const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*,
                              float*, void*, void*, hipStream_t);
 void n3dt_launch_train16_bwd(const N3dtGeom*, const N3dtMlpParams*, const N3dtMlpGrads*, const float*, const float*, const float*,
-                             const float*, const float*, const float*, const float*, const void*, float*, float*, float*, float*, void*,
-                             hipStream_t);
+                             const float*, const float*, const float*, const float*, const void*, float*, float*, float*, float*,
+                             const float*, const float*, const float*, const float*, const float*, float*, float*, void*, hipStream_t);
 void n3dt_launch_loss_fwd(int, int, const float*, const float*, const float*, const float*, float, float*, float*, hipStream_t);
 void n3dt_launch_loss_bwd(int, int, const float*, const float*, const float*, const float*, float, const float*, const float*, float*,
                           float*, hipStream_t);
@@ -308,9 +308,8 @@ extern "C" int n3dt_render_bwd(const N3dtGeom* g, int precision, const N3dtMlpPa
     if (workspace_bytes < n3dt_render_train_workspace_bytes(g)) return fail(N3DT_EWORKSPACE, "n3dt_render_bwd: workspace too small");
     if ((d_R || d_T) && (!xy || !R || !T || !Kinv)) return fail(N3DT_EINVAL, "n3dt_render_bwd: camera gradients need xy, R, T, Kinv");
     if (precision == N3DT_BF16) {
-        if (d_R || d_T) return fail(N3DT_EINVAL, "n3dt_render_bwd: camera gradients are produced by the N3DT_F32 training path only");
         n3dt_launch_train16_bwd(g, p, grads, shape, appea, audio, bg_featmap, d_merge_feat, d_fg_feat, d_bg_alpha, saved, d_bg_featmap,
-                                d_shape, d_appea, d_audio, workspace, (hipStream_t)stream);
+                                d_shape, d_appea, d_audio, xy, R, T, Kinv, t_rand, d_R, d_T, workspace, (hipStream_t)stream);
         return check_hip("n3dt_render_bwd");
     }
     n3dt_launch_train_bwd(g, p, grads, shape, appea, audio, bg_featmap, d_merge_feat, d_fg_feat, d_bg_alpha, (const float*)saved,

@@ -178,9 +178,8 @@ class _RenderFn(torch.autograd.Function):
         ws = [t.detach().view(t.shape[0], -1).contiguous() for t in mlp[:12]]
         bs = [t.detach().contiguous() for t in mlp[12:]]
         params = ops.mlp_params(ws, bs)
-        # "bf16" = the fused mixed-precision path (bf16 MFMA products, fp32 parameters and gradients).  It does not
-        # produce camera gradients: a call that needs them (single-image fitting) takes the exact fp32 path.
-        ctx.prec = _lib.F32 if ctx.want_cam else _lib.PRECISIONS[net.train_precision]
+        # "bf16" = the fused mixed-precision path (bf16 MFMA products, fp32 parameters and gradients)
+        ctx.prec = _lib.PRECISIONS[net.train_precision]
         packed = net._packed(geom, ctx.prec, params, ws, bs)
         shape_c, appea_c = ops._f32c(shape), ops._f32c(appea)
         audio_c = ops._f32c(audio) if geom.audio_dim > 0 else None

@@ -235,31 +235,20 @@ def test_fused_bf16_training_path_against_the_fp32_path(fs, ns, B):
         assert float((a * b).sum() / (a.norm() * b.norm() + 1e-30)) >= 0.995, k
 
 
-def test_bf16_training_takes_the_fp32_path_when_camera_gradients_are_requested():
-    """Single-image fitting differentiates the cameras; the fused bf16 path does not produce those gradients, so such a
-    call runs the exact path -- bit-identical to train_precision="fp32"."""
+def test_fused_bf16_camera_gradients_against_the_fp32_path():
+    """Single-image fitting differentiates the cameras.  In the fused bf16 path d PE comes from two extra
+    stages of the dX chain.  The camera gradients weight d PE by the encoder's 2^k (up to 512) and sum with heavy cancellation
+    over every sample, so the ~1 % bf16 rounding of d PE shows as up to ~25 % of the tensor's scale per entry while the
+    direction holds (cosine >= 0.99 measured; asserted >= 0.98 and <= 35 %).  The exact path is the one pinned against the
+    reference's autograd above."""
     from n3dt import BaseOptions, synthetic as syn
-    opt = BaseOptions({"featmap_size": 8, "featmap_nc": 256, "pred_img_size": 32, "num_sample_coarse": 8})
-    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
-    t_rand = syn.stratified_noise(2, 64, 8, 7).to(dev())
-    _, g32 = _grads(opt, sd, 2, "fp32", t_rand, cam=True)
-    _, g16 = _grads(opt, sd, 2, "bf16", t_rand, cam=True)
-    for k in ("batch_Rmats", "batch_Tvecs", "shape_code"):
-        torch.testing.assert_close(g16[k], g32[k], rtol=1e-5, atol=1e-9)
-
-
-def test_render_bwd_refuses_camera_gradients_in_bf16():
-    import ctypes
-    from n3dt import _lib, ops
-    L = _lib.lib()
-    g = ops.make_geom(1, 64, 8, 384, 256, 179, 127, 64, 8, 2, 2.5, -3.5)
-    t = torch.zeros(16, device=dev())
-    mp = ops.mlp_params([t] * 12, [t] * 12)
-    sb = L.n3dt_render_train_saved_bytes(ctypes.byref(g))
-    wb = L.n3dt_render_train_workspace_bytes(ctypes.byref(g))
-    saved = torch.empty(sb, dtype=torch.uint8, device=dev())
-    ws = torch.empty(wb, dtype=torch.uint8, device=dev())
-    P = ops._ptr
-    rc = L.n3dt_render_bwd(ctypes.byref(g), _lib.BF16, ctypes.byref(mp), ctypes.byref(mp), P(t), P(t), P(t), P(t), P(t), None, None,
-                           P(saved), sb, P(t), P(t), P(t), P(t), P(t), P(t), P(t), P(t), None, P(t), P(t), P(ws), wb, None)
-    assert rc != 0 and b"camera" in L.n3dt_last_error()
+    for fs, ns, B in ((8, 8, 2), (16, 64, 2)):
+        opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": fs * 4, "num_sample_coarse": ns})
+        sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
+        t_rand = syn.stratified_noise(B, fs * fs, ns, 7).to(dev())
+        _, g32 = _grads(opt, sd, B, "fp32", t_rand, cam=True)
+        _, g16 = _grads(opt, sd, B, "bf16", t_rand, cam=True)
+        for k in ("batch_Rmats", "batch_Tvecs", "shape_code"):
+            a, b = g32[k].double().flatten(), g16[k].double().flatten()
+            assert float((a - b).abs().max()) <= (0.05 if k == "shape_code" else 0.35) * float(a.abs().max()), (k, fs)
+            assert float((a * b).sum() / (a.norm() * b.norm() + 1e-30)) >= 0.98, (k, fs)
