@@ -27,7 +27,7 @@ size_t n3dt_train_saved_floats(const N3dtGeom*);
 size_t n3dt_train_ws_floats(const N3dtGeom*);
 void n3dt_launch_train_fwd(const N3dtGeom*, const N3dtMlpParams*, const float*, const float*, const float*, const float*, const float*,
                            const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, float*,
-                           float*, int, hipStream_t);
+                           float*, hipStream_t);
 void n3dt_launch_train_bwd(const N3dtGeom*, const N3dtMlpParams*, const N3dtMlpGrads*, const float*, const float*, const float*,
                            const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*,
                            const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, hipStream_t);
@@ -285,7 +285,7 @@ extern "C" int n3dt_render_train_fwd(const N3dtGeom* g, int precision, const voi
         return check_hip("n3dt_render_train_fwd");
     }
     n3dt_launch_train_fwd(g, p, tail, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap, fg_feat, bg_alpha, depth, merge_feat,
-                          (float*)saved, (float*)workspace, 0, (hipStream_t)stream);
+                          (float*)saved, (float*)workspace, (hipStream_t)stream);
     return check_hip("n3dt_render_train_fwd");
 }
 
@@ -313,7 +313,7 @@ extern "C" int n3dt_render_bwd(const N3dtGeom* g, int precision, const N3dtMlpPa
         return check_hip("n3dt_render_bwd");
     }
     n3dt_launch_train_bwd(g, p, grads, shape, appea, audio, bg_featmap, d_merge_feat, d_fg_feat, d_bg_alpha, (const float*)saved,
-                          d_bg_featmap, d_shape, d_appea, d_audio, xy, R, T, Kinv, t_rand, d_R, d_T, (float*)workspace, 0,
+                          d_bg_featmap, d_shape, d_appea, d_audio, xy, R, T, Kinv, t_rand, d_R, d_T, (float*)workspace,
                           (hipStream_t)stream);
     return check_hip("n3dt_render_bwd");
 }

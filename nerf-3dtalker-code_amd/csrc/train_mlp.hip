@@ -1,10 +1,10 @@
 // Training path of the volumetric render: forward that keeps the per-layer
 // activations, and the backward through compositing, the MLP and the latent folding.
 //
-// First version: exact fp32, layer by layer on point-major activations [P][C] in HBM, every product a
+// This file: the exact-fp32 path, layer by layer on point-major activations [P][C] in HBM, every product a
 // launch of the generic fp32 MFMA GEMM (gemm32.h).  It trades the fused kernel's zero-traffic design for
-// a backward that is simple to verify against the reference's autograd (tests/golden grad fixtures); the
-// inference path is unaffected.  Fusing the backward chain is the named next step.
+// a backward that is simple to verify against the reference's autograd (tests/golden grad fixtures).
+// The fused mixed-precision path (bf16 MFMA, fp32 gradients) lives in train_x16.inc, included at the end.
 //
 // Reference code differentiated here: NetWorks/models.py:62-87 (MLP), NetWorks/utils.py:268-309
 // (compositing), NetWorks/HeadNeRFNet.py:84-112,149-152 (latent concat, merge).
@@ -524,7 +524,7 @@ static int split_for(long K) {
 extern "C" void n3dt_launch_train_fwd(const N3dtGeom* g, const N3dtMlpParams* p, const float* tail, const float* xy, const float* R,
                                       const float* T, const float* Kinv, const float* shape, const float* appea, const float* audio,
                                       const float* t_rand, const float* bg_featmap, float* fg_feat, float* bg_alpha, float* depth,
-                                      float* merge_feat, float* saved, float* ws, int bf16, hipStream_t s) {
+                                      float* merge_feat, float* saved, float* ws, hipStream_t s) {
     const TrainSaved sv = saved_layout(g);
     const TrainWs wl = ws_layout(g);
     const int P = g->batch * g->n_rays * g->n_samples, ppf = g->n_rays * g->n_samples;
@@ -542,23 +542,23 @@ extern "C" void n3dt_launch_train_fwd(const N3dtGeom* g, const N3dtMlpParams* p,
     {
         Gemm32 q = mk(P, 384, 63, cat5, 448, 0, p->weight[0], 63 + S + U, 0, hptr(0), hld(0));
         q.bias = fold + n3dt_bias_offset(0); q.bias_group_rows = ppf; q.bias_ld = N3DT_FOLD_STRIDE; q.act = G32_ACT_RELU;
-        n3dt_gemm(q, bf16, s);
+        n3dt_gemm32(q, s);
     }
     for (int l = 1; l < 8; ++l) {
         Gemm32 q = l == 5 ? mk(P, 384, 448, cat5, 448, 0, ws + wl.w5p, 448, 0, hptr(5), hld(5))
                           : mk(P, 384, 384, hptr(l - 1), hld(l - 1), 0, p->weight[l], 384, 0, hptr(l), hld(l));
         q.bias = fold + n3dt_bias_offset(l); q.bias_group_rows = ppf; q.bias_ld = N3DT_FOLD_STRIDE; q.act = G32_ACT_RELU;
-        n3dt_gemm(q, bf16, s);
+        n3dt_gemm32(q, s);
     }
     {   // RGB_layer_0 | density_module (models.py:78-79)
         Gemm32 q = mk(P, 385, 384, hptr(7), 384, 0, ws + wl.wc, 384, 0, saved + sv.xr, XR_LD);
         q.bias = ws + wl.bc;
-        n3dt_gemm(q, bf16, s);
+        n3dt_gemm32(q, s);
     }
     {   // RGB_layer_1 (+ folded appearance), relu (models.py:80-81)
         Gemm32 q = mk(P, 192, 384, saved + sv.xr, XR_LD, 0, p->weight[10], 384 + A, 0, saved + sv.g, 192);
         q.bias = fold + n3dt_bias_offset(10); q.bias_group_rows = ppf; q.bias_ld = N3DT_FOLD_STRIDE; q.act = G32_ACT_RELU;
-        n3dt_gemm(q, bf16, s);
+        n3dt_gemm32(q, s);
     }
     const long Rr = (long)g->batch * g->n_rays;
     hipLaunchKernelGGL(train_composite_fwd_kernel, dim3((unsigned)((Rr + 3) / 4)), dim3(256), 0, s, *g, saved + sv.xr, saved + sv.g,
@@ -570,7 +570,7 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
                                       const float* appea, const float* audio, const float* bg_featmap, const float* d_merge,
                                       const float* d_fg, const float* d_ba, const float* saved, float* d_bg_featmap, float* d_shape,
                                       float* d_appea, float* d_audio, const float* xy, const float* Rm, const float* Tv,
-                                      const float* Kinv, const float* t_rand, float* d_R, float* d_T, float* ws, int bf16, hipStream_t s) {
+                                      const float* Kinv, const float* t_rand, float* d_R, float* d_T, float* ws, hipStream_t s) {
     const TrainSaved sv = saved_layout(g);
     const TrainWs wl = ws_layout(g);
     const int P = g->batch * g->n_rays * g->n_samples, ppf = g->n_rays * g->n_samples;
@@ -602,7 +602,7 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
     {   // dW2[256][192] += dfg_total^T Gray
         Gemm32 q = mk(256, 192, (int)Rr, dfg_total, 256, 1, saved + sv.ray, N3DT_PART_STRIDE, 1, gp->weight[11], 192);
         set_grad_split(q, Rr);
-        n3dt_gemm(q, bf16, s);
+        n3dt_gemm32(q, s);
     }
     // ---- compositing
     hipLaunchKernelGGL(train_composite_bwd_kernel, dim3((unsigned)((Rr + 3) / 4)), dim3(256), 0, s, *g, saved + sv.xr, saved + sv.g,
@@ -610,20 +610,20 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
     // ---- RGB_layer_1
     {
         Gemm32 q = mk(P, 384, 192, dG, 192, 0, p->weight[10], 384 + A, 1, dxr, XR_LD);  // dX = dG Wr1[:, 0:384]
-        n3dt_gemm(q, bf16, s);
+        n3dt_gemm32(q, s);
         Gemm32 w = mk(192, 384, P, dG, 192, 1, saved + sv.xr, XR_LD, 1, gp->weight[10], 384 + A);  // dWr1[:, 0:384] += dG^T X
         set_grad_split(w, P);
-        n3dt_gemm(w, bf16, s);
+        n3dt_gemm32(w, s);
         launch_colsum(dG, 192L, ppf, B, 192, dfold + n3dt_bias_offset(10), (long)N3DT_FOLD_STRIDE, s);
     }
     // ---- RGB_layer_0 | density: dH7 = dXR Wc, gated by relu(H7)
     {
         Gemm32 q = mk(P, 384, 385, dxr, XR_LD, 0, ws + wl.wc, 384, 1, dha, 384);
         q.gate = hptr(7); q.ldgate = hld(7); q.gate_act = G32_ACT_RELU;
-        n3dt_gemm(q, bf16, s);
+        n3dt_gemm32(q, s);
         Gemm32 w = mk(385, 384, P, dxr, XR_LD, 1, hptr(7), hld(7), 1, ws + wl.dwc, 384);
         set_grad_split(w, P);
-        n3dt_gemm(w, bf16, s);
+        n3dt_gemm32(w, s);
         // bias grads of RGB_layer_0 (cols 0..383) and density (col 384): one frame group of all rows
         launch_colsum(dxr, (long)XR_LD, P, 1, 385, ws + wl.bc, 0L, s);  // [d br0 (384) | d bd] into the packed scratch, copied out below
     }
@@ -635,15 +635,15 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
         if (l == 5) {
             Gemm32 w = mk(384, 448, P, dcur, 384, 1, cat5, 448, 1, ws + wl.dw5p, 448);
             set_grad_split(w, P);
-            n3dt_gemm(w, bf16, s);
+            n3dt_gemm32(w, s);
         } else if (l == 0) {
             Gemm32 w = mk(384, 63, P, dcur, 384, 1, cat5, 448, 1, gp->weight[0], 63 + S + U);
             set_grad_split(w, P);
-            n3dt_gemm(w, bf16, s);
+            n3dt_gemm32(w, s);
         } else {
             Gemm32 w = mk(384, 384, P, dcur, 384, 1, hptr(l - 1), hld(l - 1), 1, gp->weight[l], 384);
             set_grad_split(w, P);
-            n3dt_gemm(w, bf16, s);
+            n3dt_gemm32(w, s);
         }
         if (l == 0 || l == 5) {
             launch_colsum(dcur, 384L, ppf, B, 384, dfold + n3dt_bias_offset(l), (long)N3DT_FOLD_STRIDE, s);
@@ -653,12 +653,12 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
         const bool want_cam = d_R || d_T;
         if (want_cam && l == 5) {  // d PE from the skip layer: dH5 W5'[:, 0:64]
             Gemm32 q = mk(P, 64, 384, dcur, 384, 0, ws + wl.w5p, 448, 1, ws + wl.dpe, 64);
-            n3dt_gemm(q, bf16, s);
+            n3dt_gemm32(q, s);
         }
         if (want_cam && l == 0) {  // += dH0 W0[:, 0:63]
             Gemm32 q = mk(P, 63, 384, dcur, 384, 0, p->weight[0], 63 + S + U, 1, ws + wl.dpe, 64);
             q.accumulate = 1;
-            n3dt_gemm(q, bf16, s);
+            n3dt_gemm32(q, s);
             if (d_R) (void)hipMemsetAsync(d_R, 0, sizeof(float) * 9 * B, s);
             if (d_T) (void)hipMemsetAsync(d_T, 0, sizeof(float) * 3 * B, s);
             hipLaunchKernelGGL(train_camera_bwd_kernel, dim3((unsigned)((Rr + 3) / 4)), dim3(256), 0, s, *g, xy, Rm, Tv, Kinv, t_rand, cat5,
@@ -669,7 +669,7 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
         Gemm32 q = l == 5 ? mk(P, 384, 384, dcur, 384, 0, ws + wl.w5p + 64, 448, 1, dnext, 384)
                           : mk(P, 384, 384, dcur, 384, 0, p->weight[l], 384, 1, dnext, 384);
         q.gate = hptr(l - 1); q.ldgate = hld(l - 1); q.gate_act = G32_ACT_RELU;
-        n3dt_gemm(q, bf16, s);
+        n3dt_gemm32(q, s);
         float* t = dcur; dcur = dnext; dnext = t;
     }
     hipLaunchKernelGGL(train_unpack_grads_kernel, dim3((384 * 448 + 255) / 256), dim3(256), 0, s, *gp, S, ws + wl.dw5p, ws + wl.dwc,
