@@ -30,7 +30,7 @@ void n3dt_launch_train_fwd(const N3dtGeom*, const N3dtMlpParams*, const float*, 
                            float*, hipStream_t);
 void n3dt_launch_train_bwd(const N3dtGeom*, const N3dtMlpParams*, const N3dtMlpGrads*, const float*, const float*, const float*,
                            const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*,
-                           const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, hipStream_t);
+                           const float*, const float*, const float*, const float*, const float*, float*, float*, float*, hipStream_t);
 size_t n3dt_train16_saved_bytes(const N3dtGeom*);
 size_t n3dt_train16_ws_bytes(const N3dtGeom*);
 void n3dt_launch_train16_fwd(const N3dtGeom*, const N3dtMlpParams*, const void*, const float*, const float*, const float*, const float*,
