@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--rays", default="R", choices=["R", "N"],
                     help="R: rays = featmap_size^2 (reference-faithful); N: 512^2 rays, feature stage only")
@@ -110,7 +110,7 @@ def main():
     args = ap.parse_args()
     if args.config != "cfg2":
         args.no_cpu_baseline = True  # the reported CPU baseline is the headline workload's
-        if args.batch == 8:
+        if args.batch == 16:
             args.batch = 4
 
     import numpy as np
