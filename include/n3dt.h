@@ -126,7 +126,7 @@ int n3dt_mlp_pack(const N3dtGeom* g, int precision, const N3dtMlpParams* p, void
  *   t_rand  [B,N_r,N_s+1] uniform noise for mode=="train" (utils.py:73-78), NULL for "test";
  *           with g->z_planes_given: the sample planes themselves (see N3dtGeom)
  *   bg_featmap  neural_render.bg_featmap [C, N_r] (NCHW parameter), NULL to skip the merge
- * outputs (any may be NULL except fg_feat):
+ * outputs (any may be NULL, but one of fg_feat / merge_feat must be given):
  *   fg_feat [B,N_r,C]  bg_alpha [B,N_r]  depth [B,N_r]  weight [B,N_r,N_s]
  *   merge_feat [B,N_r,C] = fg_feat + bg_alpha * bg_featmap
  * `saved` (nullable, n3dt_render_saved_bytes) receives what n3dt_render_bwd needs. */

@@ -12,8 +12,10 @@
 extern "C" {
 void n3dt_launch_pack(const N3dtGeom*, int, const N3dtMlpParams*, void*, hipStream_t);
 void n3dt_launch_fold(const N3dtGeom*, const N3dtMlpParams*, const float*, const float*, const float*, float*, int, hipStream_t);
-void n3dt_launch_ray_head(const N3dtGeom*, int, int, const float*, const float*, const float*, const float*, float*, float*,
+void n3dt_launch_ray_head(const N3dtGeom*, int, int, const float*, const float*, const float*, const float*, int, float*, float*,
                           float*, float*, float*, hipStream_t);
+void n3dt_launch_ray_head_mfma(const N3dtGeom*, int, int, const float*, const float*, const float*, const float*, int, float*, float*,
+                               float*, float*, float*, float*, hipStream_t);
 void n3dt_launch_chw_to_hwc(int, int, const float*, float*, hipStream_t);
 void n3dt_launch_fine_sample(const N3dtGeom*, int, const float*, const float*, const float*, const float*, float*, hipStream_t);
 void n3dt_launch_nerf_fwd_f32(const N3dtGeom*, const N3dtMlpParams*, const void*, const float*, const float*, const float*,
@@ -95,7 +97,7 @@ static inline int block_samples(int precision) { return precision == N3DT_F32 ? 
 static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct RenderCarve {
-    size_t fold, part, wlocal, total;  // byte offsets / total bytes
+    size_t fold, part, wlocal, bghwc, total;  // byte offsets / total bytes
     int bpr, bs;
 };
 
@@ -107,7 +109,8 @@ static RenderCarve render_carve(const N3dtGeom* g, int precision) {
     c.fold = 0;
     c.part = align256((size_t)g->batch * N3DT_FOLD_STRIDE * sizeof(float));
     c.wlocal = c.part + align256(blocks * (192 + 4) * sizeof(float));
-    c.total = c.wlocal + align256(blocks * c.bs * sizeof(float));
+    c.bghwc = c.wlocal + align256(blocks * c.bs * sizeof(float));  // the background map transposed to [N_r][C] for the merge
+    c.total = c.bghwc + align256((size_t)g->n_rays * g->feat_nc * sizeof(float));
     return c;
 }
 
@@ -171,8 +174,9 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
                                size_t workspace_bytes, void* stream) {
     int rc = check_geom(g, precision);
     if (rc) return rc;
-    if (!packed_mlp || !p || !xy || !R || !T || !Kinv || !shape || !appea || !fg_feat || !workspace)
+    if (!packed_mlp || !p || !xy || !R || !T || !Kinv || !shape || !appea || !workspace)
         return fail(N3DT_EINVAL, "n3dt_render_fwd: NULL argument");
+    if (!fg_feat && !merge_feat) return fail(N3DT_EINVAL, "n3dt_render_fwd: neither fg_feat nor merge_feat requested");
     if (g->audio_dim > 0 && !audio) return fail(N3DT_EINVAL, "n3dt_render_fwd: audio is NULL but audio_dim > 0");
     if (merge_feat && !bg_featmap) return fail(N3DT_EINVAL, "n3dt_render_fwd: merge_feat needs bg_featmap");
     if (g->z_planes_given && !t_rand) return fail(N3DT_EINVAL, "n3dt_render_fwd: z_planes_given but no planes passed as t_rand");
@@ -198,7 +202,12 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
         ++g_prof_n;
     }
     const float* tail = (const float*)((const unsigned char*)packed_mlp + n3dt_packed_tail_offset(precision));
-    n3dt_launch_ray_head(g, c.bpr, c.bs, part, wlocal, tail, bg_featmap, fg_feat, bg_alpha, depth, weight, merge_feat, s);
+    float* bghwc = (float*)(ws + c.bghwc);
+    if (merge_feat) n3dt_launch_chw_to_hwc(g->feat_nc, g->n_rays, bg_featmap, bghwc, s);  // [C][N_r] parameter -> [N_r][C]
+    if (precision == N3DT_F32)
+        n3dt_launch_ray_head(g, c.bpr, c.bs, part, wlocal, tail, bghwc, 1, fg_feat, bg_alpha, depth, weight, merge_feat, s);
+    else
+        n3dt_launch_ray_head_mfma(g, c.bpr, c.bs, part, wlocal, tail, bghwc, 1, fg_feat, bg_alpha, depth, weight, merge_feat, nullptr, s);
     return check_hip("n3dt_render_fwd");
 }
 

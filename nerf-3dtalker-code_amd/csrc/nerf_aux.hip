@@ -211,10 +211,10 @@ extern "C" void n3dt_launch_fold(const N3dtGeom* g, const N3dtMlpParams* p, cons
 // 8 rays per 256-thread workgroup, thread = output channel.
 // ---------------------------------------------------------------------------------------------
 #define HEAD_RAYS 8
-#define HEAD_MAX_BPR 16
+#define HEAD_MAX_BPR 64  // n_samples <= 1024 (n3dt_api.hip) over 16-sample blocks
 __global__ __launch_bounds__(256) void ray_head_kernel(N3dtGeom g, int bpr, int bs, const float* __restrict__ part,
                                                        const float* __restrict__ wlocal, const float* __restrict__ tail,
-                                                       const float* __restrict__ bg_featmap, float* __restrict__ fg_feat,
+                                                       const float* __restrict__ bg_featmap, int bg_hwc, float* __restrict__ fg_feat,
                                                        float* __restrict__ bg_alpha, float* __restrict__ depth,
                                                        float* __restrict__ weight, float* __restrict__ merge_feat,
                                                        float* __restrict__ rayrec) {
@@ -274,10 +274,11 @@ __global__ __launch_bounds__(256) void ray_head_kernel(N3dtGeom g, int bpr, int 
         if (rg >= nrays_total) break;
         float fg = acc[r] + b2 * wsum_s[r];
         float ba = 1.0f - wsum_s[r];
-        fg_feat[(size_t)rg * N3DT_C + t] = fg;
+        if (fg_feat) fg_feat[(size_t)rg * N3DT_C + t] = fg;
         if (merge_feat) {
             int ray = (int)(rg % g.n_rays);
-            merge_feat[(size_t)rg * N3DT_C + t] = fg + ba * bg_featmap[(size_t)t * g.n_rays + ray];
+            // bg_hwc: the background map transposed to [N_r][C] (coalesced here); else the parameter's own [C][N_r]
+            merge_feat[(size_t)rg * N3DT_C + t] = fg + ba * (bg_hwc ? bg_featmap[(size_t)ray * N3DT_C + t] : bg_featmap[(size_t)t * g.n_rays + ray]);
         }
         if (t == 0) {
             if (bg_alpha) bg_alpha[rg] = ba;
@@ -296,13 +297,144 @@ __global__ __launch_bounds__(256) void ray_head_kernel(N3dtGeom g, int bpr, int 
     }
 }
 
+// The same head on the matrix pipe (16-bit render modes): 32 rays per workgroup; RGB_layer_2 as a 32 x 192 x 256 product on
+// v_mfma_f32_32x32x16_bf16 with BOTH factors split into bf16 hi + lo (three products: hi*hi + hi*lo + lo*hi), i.e. ~16
+// mantissa bits -- far inside the 16-bit modes' error budget; the fp32 parity mode keeps the FMA kernel above.
+// The FMA kernel is VALU-bound (1 536 FMAs per thread): 100 us per 32 768 rays, 2 % of the render step.
+typedef __bf16 rh_bf16x8 __attribute__((ext_vector_type(8)));
+#define RH_RAYS 32
+__global__ __launch_bounds__(256) void ray_head_mfma_kernel(N3dtGeom g, int bpr, int bs, const float* __restrict__ part,
+                                                            const float* __restrict__ wlocal, const float* __restrict__ tail,
+                                                            const float* __restrict__ bg_featmap, int bg_hwc,
+                                                            float* __restrict__ fg_feat, float* __restrict__ bg_alpha,
+                                                            float* __restrict__ depth, float* __restrict__ weight,
+                                                            float* __restrict__ merge_feat, float* __restrict__ rayrec) {
+    __shared__ __attribute__((aligned(16))) float G[RH_RAYS][N3DT_G + 4];  // +4: 16-byte aligned rows off the bank stride
+    __shared__ float pref[RH_RAYS][HEAD_MAX_BPR];
+    __shared__ float wsum_s[RH_RAYS], dsum_s[RH_RAYS];
+    const long nrays_total = (long)g.batch * g.n_rays;
+    const long ray0 = (long)blockIdx.x * RH_RAYS;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t < RH_RAYS) {
+        const long rg = ray0 + t;
+        float Trun = 1.0f, ws = 0.0f, ds = 0.0f;
+        if (rg < nrays_total) {
+            for (int k = 0; k < bpr; ++k) {
+                const float* po = part + ((size_t)rg * bpr + k) * N3DT_PART_STRIDE + N3DT_G;
+                pref[t][k] = Trun;
+                ws += Trun * po[0];
+                ds += Trun * po[1];
+                Trun *= po[2];
+            }
+        }
+        wsum_s[t] = ws;
+        dsum_s[t] = ds;
+    }
+    __syncthreads();
+    for (int i = t; i < RH_RAYS * N3DT_G; i += 256) {
+        const int r = i / N3DT_G, j = i % N3DT_G;
+        const long rg = ray0 + r;
+        float acc = 0.0f;
+        if (rg < nrays_total)
+            for (int k = 0; k < bpr; ++k) acc += pref[r][k] * part[((size_t)rg * bpr + k) * N3DT_PART_STRIDE + j];
+        G[r][j] = acc;
+        if (rayrec && rg < nrays_total) rayrec[(size_t)rg * N3DT_PART_STRIDE + j] = acc;
+    }
+    __syncthreads();
+    if (rayrec && t < RH_RAYS && ray0 + t < nrays_total) {
+        float* rec = rayrec + (size_t)(ray0 + t) * N3DT_PART_STRIDE + N3DT_G;
+        rec[0] = wsum_s[t];
+        rec[1] = dsum_s[t];
+        rec[2] = 0.0f;
+        rec[3] = 0.0f;
+    }
+    // fg[ray][c] = sum_j G[ray][j] W2T[j][c]: wave w owns output channels 64 w .. 64 w + 63 (two 32-column tiles)
+    const int r31 = lane & 31, h = lane >> 5;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const float* W2T = tail;
+#pragma unroll 2
+    for (int ks = 0; ks < N3DT_G / 16; ++ks) {
+        const int k0 = 16 * ks + 8 * h;
+        rh_bf16x8 a_hi, a_lo;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(&G[r31][k0]), g1 = *reinterpret_cast<const f32x4*>(&G[r31][k0 + 4]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = j < 4 ? g0[j] : g1[j - 4];
+            const __bf16 hi = (__bf16)v;
+            a_hi[j] = hi;
+            a_lo[j] = (__bf16)(v - (float)hi);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int col = 64 * wave + 32 * i + r31;
+            rh_bf16x8 b_hi, b_lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = W2T[(size_t)(k0 + j) * N3DT_C + col];
+                const __bf16 hi = (__bf16)v;
+                b_hi[j] = hi;
+                b_lo[j] = (__bf16)(v - (float)hi);
+            }
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[i], 0, 0, 0);
+        }
+    }
+    // accumulator tile: column (output channel) on the lane, rays in the registers
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = 64 * wave + 32 * i + r31;
+        const float b2 = tail[N3DT_G * N3DT_C + c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const long rg = ray0 + rr;
+            if (rg >= nrays_total) continue;
+            const float fg = acc[i][r] + b2 * wsum_s[rr];
+            if (fg_feat) fg_feat[(size_t)rg * N3DT_C + c] = fg;
+            if (merge_feat) {
+                const int ray = (int)(rg % g.n_rays);
+                merge_feat[(size_t)rg * N3DT_C + c] =
+                    fg + (1.0f - wsum_s[rr]) * (bg_hwc ? bg_featmap[(size_t)ray * N3DT_C + c] : bg_featmap[(size_t)c * g.n_rays + ray]);
+            }
+        }
+    }
+    if (t < RH_RAYS && ray0 + t < nrays_total) {
+        if (bg_alpha) bg_alpha[ray0 + t] = 1.0f - wsum_s[t];
+        if (depth) depth[ray0 + t] = dsum_s[t];
+    }
+    if (weight) {
+        for (int i = t; i < RH_RAYS * g.n_samples; i += 256) {
+            const int r = i / g.n_samples, s = i % g.n_samples;
+            const long rg = ray0 + r;
+            if (rg < nrays_total) {
+                const int k = s / bs;
+                weight[(size_t)rg * g.n_samples + s] = pref[r][k] * wlocal[((size_t)rg * bpr + k) * bs + (s % bs)];
+            }
+        }
+    }
+}
+
+extern "C" void n3dt_launch_ray_head_mfma(const N3dtGeom* g, int bpr, int bs, const float* part, const float* wlocal,
+                                          const float* tail, const float* bg_featmap, int bg_hwc, float* fg_feat, float* bg_alpha,
+                                          float* depth, float* weight, float* merge_feat, float* rayrec, hipStream_t stream) {
+    const long nrays_total = (long)g->batch * g->n_rays;
+    const int grid = (int)((nrays_total + RH_RAYS - 1) / RH_RAYS);
+    hipLaunchKernelGGL(ray_head_mfma_kernel, dim3(grid), dim3(256), 0, stream, *g, bpr, bs, part, wlocal, tail,
+                       merge_feat ? bg_featmap : nullptr, bg_hwc, fg_feat, bg_alpha, depth, weight, merge_feat, rayrec);
+}
+
 extern "C" void n3dt_launch_ray_head(const N3dtGeom* g, int bpr, int bs, const float* part, const float* wlocal,
-                                     const float* tail, const float* bg_featmap, float* fg_feat, float* bg_alpha, float* depth,
-                                     float* weight, float* merge_feat, hipStream_t stream) {
+                                     const float* tail, const float* bg_featmap, int bg_hwc, float* fg_feat, float* bg_alpha,
+                                     float* depth, float* weight, float* merge_feat, hipStream_t stream) {
     const long nrays_total = (long)g->batch * g->n_rays;
     const int grid = (int)((nrays_total + HEAD_RAYS - 1) / HEAD_RAYS);
     hipLaunchKernelGGL(ray_head_kernel, dim3(grid), dim3(256), 0, stream, *g, bpr, bs, part, wlocal, tail,
-                       merge_feat ? bg_featmap : nullptr, fg_feat, bg_alpha, depth, weight, merge_feat, (float*)nullptr);
+                       merge_feat ? bg_featmap : nullptr, bg_hwc, fg_feat, bg_alpha, depth, weight, merge_feat, (float*)nullptr);
 }
 
 // training forward: also leaves the per-ray record [R][N3DT_PART_STRIDE] and the global sample weights behind
@@ -312,7 +444,7 @@ extern "C" void n3dt_launch_ray_head_rec(const N3dtGeom* g, int bpr, int bs, con
     const long nrays_total = (long)g->batch * g->n_rays;
     const int grid = (int)((nrays_total + HEAD_RAYS - 1) / HEAD_RAYS);
     hipLaunchKernelGGL(ray_head_kernel, dim3(grid), dim3(256), 0, stream, *g, bpr, bs, part, wlocal, tail,
-                       merge_feat ? bg_featmap : nullptr, fg_feat, bg_alpha, depth, weight, merge_feat, rayrec);
+                       merge_feat ? bg_featmap : nullptr, 0, fg_feat, bg_alpha, depth, weight, merge_feat, rayrec);
 }
 
 // [C][n] -> [n][C]

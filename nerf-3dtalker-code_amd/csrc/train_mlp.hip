@@ -491,7 +491,7 @@ __global__ void train_unpack_grads_kernel(N3dtMlpGrads gp, int S, const float* _
 // orchestration
 // ---------------------------------------------------------------------------------------------
 extern "C" void n3dt_launch_fold(const N3dtGeom*, const N3dtMlpParams*, const float*, const float*, const float*, float*, int, hipStream_t);
-extern "C" void n3dt_launch_ray_head(const N3dtGeom*, int, int, const float*, const float*, const float*, const float*, float*,
+extern "C" void n3dt_launch_ray_head(const N3dtGeom*, int, int, const float*, const float*, const float*, const float*, int, float*,
                                      float*, float*, float*, float*, hipStream_t);
 
 static Gemm32 mk(int M, int N, int K, const float* A, long lda, int ak, const float* B, long ldb, int bk, float* C, long ldc) {
@@ -563,7 +563,7 @@ extern "C" void n3dt_launch_train_fwd(const N3dtGeom* g, const N3dtMlpParams* p,
     const long Rr = (long)g->batch * g->n_rays;
     hipLaunchKernelGGL(train_composite_fwd_kernel, dim3((unsigned)((Rr + 3) / 4)), dim3(256), 0, s, *g, saved + sv.xr, saved + sv.g,
                        saved + sv.geo, saved + sv.w, saved + sv.ray);
-    n3dt_launch_ray_head(g, 1, g->n_samples, saved + sv.ray, nullptr, tail, bg_featmap, fg_feat, bg_alpha, depth, nullptr, merge_feat, s);
+    n3dt_launch_ray_head(g, 1, g->n_samples, saved + sv.ray, nullptr, tail, bg_featmap, 0, fg_feat, bg_alpha, depth, nullptr, merge_feat, s);
 }
 
 extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p, const N3dtMlpGrads* gp, const float* shape,

@@ -322,7 +322,7 @@ class HeadNeRFNet(nn.Module):
 
     def render_features(self, batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
                         t_rand=None, want_depth=False, want_weight=False, want_merge=True, precision=None, merge_out=None,
-                        z_planes=None):
+                        z_planes=None, want_fg=True):
         """Rays -> composited feature map (seams a1..a7).  Outputs are ray-major [B, N_r, C].
         z_planes [B, N_r, N+1] (from fine_planes()): the hierarchical pass -- those planes, the fine network."""
         prec = _lib.PRECISIONS[precision or self.precision]
@@ -342,7 +342,8 @@ class HeadNeRFNet(nn.Module):
                              ops._f32c(batch_inv_inmats), ops._f32c(shape_code), ops._f32c(appea_code), audio,
                              None if t_rand is None else ops._f32c(t_rand),
                              self.neural_render.bg_featmap.detach().view(self.featmap_nc, -1) if want_merge else None,
-                             want_depth=want_depth, want_weight=want_weight, want_merge=want_merge, merge_out=merge_out)
+                             want_depth=want_depth, want_weight=want_weight, want_merge=want_merge, merge_out=merge_out,
+                             want_fg=want_fg)
         return out
 
     def fine_planes(self, batch_xy, coarse_weight, batch_Tvecs, t_rand=None, fine_u=None):
@@ -378,14 +379,15 @@ class HeadNeRFNet(nn.Module):
         nb = n_pass * batch_size
         maps = torch.empty(nb + 1, fs, fs, C, dtype=torch.float32, device=batch_xy.device)
         coarse = self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
-                                      t_rand=t_rand, want_weight=self.hier_sampling, want_merge=True,
+                                      t_rand=t_rand, want_weight=self.hier_sampling, want_merge=True, want_fg=False,
                                       merge_out=maps[:batch_size].view(batch_size, fs * fs, C))
         if self.hier_sampling:
             if for_train and fine_u is None:  # the reference's torch.rand(num_temp, NFsample) (NetWorks/utils.py:227)
                 fine_u = torch.rand(batch_size * n_r, self.num_sample_fine + 1, device=batch_xy.device, dtype=torch.float32)
             planes = self.fine_planes(batch_xy, coarse["weight"], batch_Tvecs, t_rand=t_rand, fine_u=fine_u)
             self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
-                                 z_planes=planes, want_merge=True, merge_out=maps[batch_size:nb].view(batch_size, fs * fs, C))
+                                 z_planes=planes, want_merge=True, want_fg=False,
+                                 merge_out=maps[batch_size:nb].view(batch_size, fs * fs, C))
         ops.chw_to_hwc(self.neural_render.bg_featmap.detach().view(C, fs * fs), C, fs * fs, maps[nb].view(fs * fs, C))
         imgs = self.neural_render.render_hwc(maps, self.precision)
         res = {"coarse_dict": {"merge_img": imgs[:batch_size], "bg_img": imgs[nb:]}}

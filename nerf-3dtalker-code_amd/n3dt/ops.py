@@ -94,13 +94,14 @@ def pack_mlp(geom, precision, params, device):
 
 
 def render_fwd(geom, precision, packed, params, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap,
-               want_depth=False, want_weight=False, want_merge=True, merge_out=None):
-    """a1..a7 fused.  Returns dict(fg_feat [B,Nr,C], bg_alpha [B,Nr], depth?, weight?, merge_feat?)."""
+               want_depth=False, want_weight=False, want_merge=True, merge_out=None, want_fg=True):
+    """a1..a7 fused.  Returns dict(fg_feat [B,Nr,C]?, bg_alpha [B,Nr]?, depth?, weight?, merge_feat?)."""
     dev = xy.device
     B, Nr, Ns, C = geom.batch, geom.n_rays, geom.n_samples, geom.feat_nc
+    assert want_fg or want_merge
     out = {
-        "fg_feat": torch.empty(B, Nr, C, dtype=torch.float32, device=dev),
-        "bg_alpha": torch.empty(B, Nr, dtype=torch.float32, device=dev),
+        "fg_feat": torch.empty(B, Nr, C, dtype=torch.float32, device=dev) if want_fg else None,
+        "bg_alpha": torch.empty(B, Nr, dtype=torch.float32, device=dev) if want_fg else None,
         "depth": torch.empty(B, Nr, dtype=torch.float32, device=dev) if want_depth else None,
         "weight": torch.empty(B, Nr, Ns, dtype=torch.float32, device=dev) if want_weight else None,
         "merge_feat": (merge_out if merge_out is not None else torch.empty(B, Nr, C, dtype=torch.float32, device=dev))
