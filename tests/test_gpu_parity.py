@@ -172,6 +172,25 @@ def test_against_oracle_on_fresh_inputs():
     np.testing.assert_allclose(f["fg_feat"].permute(0, 2, 1).cpu().numpy(), ref["fg_feat"], atol=3e-5)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_many_samples_per_ray_against_oracle(precision):
+    """The reference's maximum the ABI accepts is 1024 samples per ray; 600 samples = 38 blocks of 16 (fp32 kernel) or 19 of
+    32 (16-bit kernels) per ray exercises the front-to-back combine of many per-block partials (the per-ray head once
+    sized its prefix table for 16 blocks)."""
+    from n3dt import BaseOptions, synthetic as syn
+    from oracle import oracle as orc
+    opt = BaseOptions({"featmap_size": 4, "featmap_nc": 256, "pred_img_size": 16, "num_sample_coarse": 600})
+    sd = syn.make_state_dict(opt, seed=5, bg_noise=0.2)
+    inp = syn.frame_inputs(opt, 2, yaw_range=0.4, first_frame=3)
+    ref = orc.forward(sd, opt, inp, None, skip_neural_render=True)
+    net = build_net(opt, sd, precision)
+    f = feats(net, to_dev(inp), want_weight=True, want_depth=True)
+    np.testing.assert_allclose(f["fg_feat"].permute(0, 2, 1).cpu().numpy(), ref["fg_feat"], atol=FEAT_TOL[precision])
+    np.testing.assert_allclose(f["bg_alpha"].cpu().numpy()[:, None], ref["bg_alpha"], atol=FEAT_TOL[precision])
+    w = f["weight"].cpu().numpy()
+    np.testing.assert_allclose(w.sum(-1) + f["bg_alpha"].cpu().numpy(), 1.0, atol=1e-4 if precision == "fp32" else 5e-3)
+
+
 def test_properties_at_full_size():
     """BASELINE full size (fs 64, 64 samples, B=8): size-independent properties instead of a stored answer."""
     from n3dt import BaseOptions, synthetic as syn
