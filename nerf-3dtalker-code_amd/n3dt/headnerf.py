@@ -164,6 +164,17 @@ class NeuralRenderer(nn.Module):
 
 
 
+def _zeros_like_many(tensors):
+    """Zeroed gradient buffers for a list of parameter tensors as views of ONE allocation (one fill kernel instead of one
+    per tensor: the training step launched 70 of them); every view starts on a 256-byte boundary."""
+    offs, total = [], 0
+    for t in tensors:
+        offs.append(total)
+        total += (t.numel() + 63) // 64 * 64
+    flat = torch.zeros(total, dtype=tensors[0].dtype, device=tensors[0].device)
+    return [flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, tensors)]
+
+
 class _RenderFn(torch.autograd.Function):
     """a1..a7 with saved activations (n3dt_render_train_fwd) and its backward (n3dt_render_bwd).
     Inputs after `net`/`geom`: xy, Kinv, t_rand (no grad), then R, T, shape, appea, audio, bg_featmap and the
@@ -195,8 +206,7 @@ class _RenderFn(torch.autograd.Function):
     def backward(ctx, d_merge):
         ws, bs, shape_c, appea_c, audio_c, bg = ctx.keep
         geom = ctx.geom
-        gws = [torch.zeros_like(w) for w in ws]
-        gbs = [torch.zeros_like(b) for b in bs]
+        gws, gbs = _zeros_like_many(ws), _zeros_like_many(bs)
         d_bg, d_shape, d_appea, d_audio, d_R, d_T = ops.render_bwd(geom, ops.mlp_params(ws, bs), ops.mlp_params(gws, gbs), shape_c,
                                                                    appea_c, audio_c, bg, d_merge.contiguous(), ctx.saved, ctx.cam, ctx.prec)
         ctx.saved = None
@@ -225,7 +235,7 @@ class _NeuralRenderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_img):
         tensors, fm = ctx.keep
-        gt = [torch.zeros_like(t) for t in tensors]
+        gt = _zeros_like_many(list(tensors))
         d_feat = ops.neural_render_bwd(ctx.geom, ctx.nb, ctx.nr._rparams_from(tensors), ctx.nr._rparams_from(gt), fm,
                                        d_img.contiguous(), ctx.saved, ctx.prec)
         ctx.saved = None
