@@ -66,18 +66,27 @@ __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >
 // tv [M][4C] (+ residual x.repeat) -> pixel-shuffled ps [4M][C]   (PixelShuffleUpsample.py:36,41-42)
 __global__ void nrt_shuffle_kernel(int nb, int H, int W, int C, const float* __restrict__ tv, const float* __restrict__ x,
                                    float* __restrict__ ps) {
-    const size_t total = (size_t)nb * H * W * 4 * C;
+    // thread = 4 adjacent output channels of one output pixel (one 16-byte store)
+    const int c4 = C >> 2;
+    const size_t total = (size_t)nb * H * W * 4 * c4;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const N3dtDiv dC = n3dt_div(C), dW2 = n3dt_div(2 * W), dH2 = n3dt_div(2 * H);
-    const int c = n3dt_rem(i, dC);
-    size_t opix = n3dt_quot(i, dC);  // output pixel
+    const N3dtDiv dc4 = n3dt_div(c4), dC = n3dt_div(C), dW2 = n3dt_div(2 * W), dH2 = n3dt_div(2 * H);
+    const int c = 4 * n3dt_rem(i, dc4);
+    size_t opix = n3dt_quot(i, dc4);  // output pixel
     const size_t orow = n3dt_quot(opix, dW2);
     const int ow = n3dt_rem(opix, dW2), oh = n3dt_rem(orow, dH2), img = (int)n3dt_quot(orow, dH2);
     const int h = oh >> 1, di = oh & 1, w = ow >> 1, dj = ow & 1;
     const size_t m = ((size_t)img * H + h) * W + w;
-    const int o = 4 * c + 2 * di + dj;
-    ps[i] = tv[m * 4 * C + o] + x[m * C + n3dt_rem(o, dC)];
+    const float* tr = tv + m * 4 * C;
+    const float* xr = x + m * C;
+    f32x4 out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int o = 4 * (c + j) + 2 * di + dj;  // pixel_shuffle source channel; x.repeat(1,4,1,1) adds x[o % C]
+        out[j] = tr[o] + xr[n3dt_rem(o, dC)];
+    }
+    *reinterpret_cast<f32x4*>(ps + opix * C + c) = out;
 }
 
 __global__ void nrt_blur_kernel(int nb, int H, int W, int C, const float* __restrict__ x, float* __restrict__ y) {
@@ -165,15 +174,14 @@ __global__ void nrt_rgb_up_kernel(int n_planes, int h, int w, const float* __res
 }
 
 // ---- backward pieces --------------------------------------------------------------------------
-// 1-D adjoint taps of the reflect-border [1,2,1]/4 blur: which outputs i read input j, with what weight
-__device__ __forceinline__ int blur_adj_taps(int j, int n, int idx[5], float wt[5]) {
-    int c = 0;
-    if (j - 1 >= 0) { idx[c] = j - 1; wt[c++] = 0.25f; }   // output j-1 reads j at d=+1
-    idx[c] = j; wt[c++] = 0.5f;
-    if (j + 1 < n) { idx[c] = j + 1; wt[c++] = 0.25f; }    // output j+1 reads j at d=-1
-    if (j == 1) { idx[c] = 0; wt[c++] = 0.25f; }           // output 0 reads reflect(-1) = 1
-    if (j == n - 2) { idx[c] = n - 1; wt[c++] = 0.25f; }   // output n-1 reads reflect(n) = n-2
-    return c;
+// 1-D adjoint of the reflect-border [1,2,1]/4 blur: which outputs read input j, with what weight.
+// In closed form: input j is read by outputs j-1, j, j+1 only (the reflected reads of outputs 0 and
+// n-1 land on j = 1 and j = n-2, i.e. on an existing neighbour), so three taps with border-dependent weights --
+// no tap lists, no variable trip counts (the list form kept its index arrays in scratch).
+__device__ __forceinline__ void blur_adj_w3(int j, int n, float (&w)[3]) {
+    w[0] = j >= 1 ? (j == 1 ? 0.5f : 0.25f) : 0.0f;           // from output j-1 (+ output 0's reflected read when j == 1)
+    w[1] = 0.5f;
+    w[2] = j + 1 < n ? (j == n - 2 ? 0.5f : 0.25f) : 0.0f;    // from output j+1 (+ output n-1's reflected read when j == n-2)
 }
 
 __global__ void nrt_blur_adj_kernel(int nb, int H, int W, int C, const float* __restrict__ dy, float* __restrict__ dx) {
@@ -185,15 +193,20 @@ __global__ void nrt_blur_adj_kernel(int nb, int H, int W, int C, const float* __
     size_t pix = n3dt_quot(i, dc4);
     const size_t prow = n3dt_quot(pix, dW);
     int w = n3dt_rem(pix, dW), h = n3dt_rem(prow, dH), img = (int)n3dt_quot(prow, dH);
-    int ih[5], iw[5];
-    float wh[5], ww[5];
-    const int nh = blur_adj_taps(h, H, ih, wh), nw = blur_adj_taps(w, W, iw, ww);
+    float wh[3], ww[3];
+    blur_adj_w3(h, H, wh);
+    blur_adj_w3(w, W, ww);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int a = 0; a < nh; ++a)
-        for (int b = 0; b < nw; ++b) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(dy + (((size_t)img * H + ih[a]) * W + iw[b]) * C + 4 * cq);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int hh = min(max(h + a - 1, 0), H - 1);  // clamped rows / columns carry weight 0
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int wc = min(max(w + b - 1, 0), W - 1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dy + (((size_t)img * H + hh) * W + wc) * C + 4 * cq);
             acc += (wh[a] * ww[b]) * v;
         }
+    }
     *reinterpret_cast<f32x4*>(dx + pix * C + 4 * cq) = acc;
 }
 
@@ -205,13 +218,17 @@ __global__ void nrt_blur_adj_planar_kernel(int n_planes, int H, int W, const flo
     const size_t prow = n3dt_quot(i, dW);
     int w = n3dt_rem(i, dW), h = n3dt_rem(prow, dH);
     size_t pl = n3dt_quot(prow, dH);
-    int ih[5], iw[5];
-    float wh[5], ww[5];
-    const int nh = blur_adj_taps(h, H, ih, wh), nw = blur_adj_taps(w, W, iw, ww);
+    float wh[3], ww[3];
+    blur_adj_w3(h, H, wh);
+    blur_adj_w3(w, W, ww);
     const float* d = dy + pl * (size_t)H * W;
     float acc = 0.0f;
-    for (int a = 0; a < nh; ++a)
-        for (int b = 0; b < nw; ++b) acc += (wh[a] * ww[b]) * d[(size_t)ih[a] * W + iw[b]];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int hh = min(max(h + a - 1, 0), H - 1);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc += (wh[a] * ww[b]) * d[(size_t)hh * W + min(max(w + b - 1, 0), W - 1)];
+    }
     dx[i] = acc;
 }
 
@@ -310,25 +327,26 @@ __global__ void nrt_add_kernel(size_t n, const float* __restrict__ a, float* __r
 }
 
 // out[n] += sum_m X[m][n]: one thread = 4 adjacent columns x a 256-row chunk, 8 independent float4 loads in flight
-#define NRT_CS_ROWS 1024
-__global__ __launch_bounds__(256) void nrt_colsum_kernel(const float* __restrict__ X, long ldx, long rows, int N, float* __restrict__ out) {
+#define NRT_CS_ROWS 512
+__global__ __launch_bounds__(256) void nrt_colsum_kernel(const float* __restrict__ X, long ldx, long rows, int N, float* __restrict__ out,
+                                                         int chunk) {
     // thread = 4 adjacent columns x one row lane (256 / (N/4) row lanes; every N here is a multiple of 32, <= 1024)
     __shared__ f32x4 red[256];
     const int cg = N >> 2, lanes = 256 / cg;
     const int t = threadIdx.x, cq = t % cg, rl = t / cg;
-    const long r0 = (long)blockIdx.x * NRT_CS_ROWS, r1 = min(rows, r0 + NRT_CS_ROWS);
+    const long r0 = (long)blockIdx.x * chunk, r1 = min(rows, r0 + chunk);
     const float* base = X + 4 * cq;
     f32x4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     long r = r0 + rl;
     if (rl < lanes) {
-        for (; r + 3L * lanes < r1; r += 4L * lanes) {
-            f32x4 v[4];
+        for (; r + 7L * lanes < r1; r += 8L * lanes) {
+            f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (r + (long)u * lanes) * ldx);
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (r + (long)u * lanes) * ldx);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] += v[u];
+            for (int u = 0; u < 8; ++u) acc[u & 3] += v[u];
         }
         for (; r < r1; r += lanes) acc[0] += *reinterpret_cast<const f32x4*>(base + r * ldx);
     }
@@ -342,7 +360,12 @@ __global__ __launch_bounds__(256) void nrt_colsum_kernel(const float* __restrict
     }
 }
 static void launch_nrt_colsum(const float* X, long ldx, long rows, int N, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(nrt_colsum_kernel, dim3((unsigned)((rows + NRT_CS_ROWS - 1) / NRT_CS_ROWS)), dim3(256), 0, s, X, ldx, rows, N, out);
+    // about 384 workgroups: every workgroup ends in N atomics on the SAME N addresses, and thousands of same-address atomics
+    // serialise (they, not the loads, set the time of the 1536-workgroup version)
+    long chunk = (rows + 383) / 384;
+    if (chunk < NRT_CS_ROWS) chunk = NRT_CS_ROWS;
+    chunk = (chunk + 31) / 32 * 32;
+    hipLaunchKernelGGL(nrt_colsum_kernel, dim3((unsigned)((rows + chunk - 1) / chunk)), dim3(256), 0, s, X, ldx, rows, N, out, (int)chunk);
 }
 
 // db[c] += sum over images and pixels of planar d_rgb
@@ -366,7 +389,7 @@ __global__ void nrt_rgb_bias_kernel(int nb, int HW, const float* __restrict__ d_
 // feat_2_rgb weight gradient: dW[k][c] += sum over images and pixels of d_rgb[img][k][pix] * net[img][pix][c]
 // (a 3 x co result over up to 10^6 pixels: a reduction, not a GEMM).  Thread = 4 adjacent channels x one pixel lane;
 // block = NRT_WG_PIX consecutive pixels of one image; co in {32, 64, 128, 256}.
-#define NRT_WG_PIX 2048
+#define NRT_WG_PIX 512
 __global__ __launch_bounds__(256) void nrt_to_rgb_wgrad_kernel(int HW, int co, const float* __restrict__ d_rgb,
                                                                const float* __restrict__ net, float* __restrict__ dW) {
     __shared__ float red[256][13];
@@ -382,17 +405,32 @@ __global__ __launch_bounds__(256) void nrt_to_rgb_wgrad_kernel(int HW, int co, c
     for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[k][j] = 0.0f;
-    for (int p = p0 + pl; p < p1; p += lanes) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)p * co);
+    auto one = [&](const int p, const f32x4 v, const float g0, const float g1, const float g2) {
+        const float gk[3] = {g0, g1, g2};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float g = d[(size_t)k * HW + p];
-            acc[k][0] = fmaf(g, v.x, acc[k][0]);
-            acc[k][1] = fmaf(g, v.y, acc[k][1]);
-            acc[k][2] = fmaf(g, v.z, acc[k][2]);
-            acc[k][3] = fmaf(g, v.w, acc[k][3]);
+            acc[k][0] = fmaf(gk[k], v.x, acc[k][0]);
+            acc[k][1] = fmaf(gk[k], v.y, acc[k][1]);
+            acc[k][2] = fmaf(gk[k], v.z, acc[k][2]);
+            acc[k][3] = fmaf(gk[k], v.w, acc[k][3]);
         }
+        (void)p;
+    };
+    int p = p0 + pl;
+    for (; p + 3 * lanes < p1; p += 4 * lanes) {  // four independent pixels in flight
+        f32x4 v[4];
+        float gg[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(p + u * lanes) * co);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gg[u][k] = d[(size_t)k * HW + p + u * lanes];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(p, v[u], gg[u][0], gg[u][1], gg[u][2]);
     }
+    for (; p < p1; p += lanes)
+        one(p, *reinterpret_cast<const f32x4*>(x + (size_t)p * co), d[p], d[(size_t)HW + p], d[(size_t)2 * HW + p]);
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -458,7 +496,7 @@ extern "C" void n3dt_launch_nr_train_fwd(const N3dtGeom* g, int nb, const N3dtRe
         Gemm32 q2 = mk(M, 4 * ci, 2 * ci, saved + sv.t1[i], 2 * ci, 0, p->psu2_w[i], 2 * ci, 0, saved + sv.tv[i], 4 * ci);
         q2.bias = p->psu2_b[i]; q2.act = G32_ACT_LRELU;
         n3dt_gemm(q2, bf16, s);
-        hipLaunchKernelGGL(nrt_shuffle_kernel, GRID1((size_t)M * 4 * ci), 0, s, nb, h, h, ci, saved + sv.tv[i], x, ps);
+        hipLaunchKernelGGL(nrt_shuffle_kernel, GRID1((size_t)M * ci), 0, s, nb, h, h, ci, saved + sv.tv[i], x, ps);
         h *= 2;
         hipLaunchKernelGGL(nrt_blur_kernel, GRID1((size_t)nb * h * h * (ci / 4)), 0, s, nb, h, h, ci, ps, saved + sv.bl[i]);
         Gemm32 q3 = mk(nb * h * h, co, ci, saved + sv.bl[i], ci, 0, p->feat_w[i], ci, 0, saved + sv.net[i], co);
