@@ -302,6 +302,7 @@ __global__ void train_composite_bwd_kernel(N3dtGeom g, const float* __restrict__
     }
 }
 
+#define CAM_RAYS 64
 // Camera backward (the single-image fitting use-case): one wave per ray.
 //   p_s = T + (d l) z_s,  dist_s = (z_{s+1} - z_s) l,  d = w/|w|,  w = R c,  c = Kinv [x, y, 1],  l = -1/d_z
 //   PE rows: [p, sin(2^k p), cos(2^k p)]  ->  dp = dPE_p + sum_k 2^k (cos * dPE_sin - sin * dPE_cos)
@@ -312,11 +313,15 @@ __global__ void train_camera_bwd_kernel(N3dtGeom g, const float* __restrict__ xy
                                         const float* __restrict__ t_rand, const float* __restrict__ cat5,
                                         const float* __restrict__ dpe, const float* __restrict__ dxr, float* __restrict__ d_R,
                                         float* __restrict__ d_T) {
-    const long Rr = (long)g.batch * g.n_rays;
-    const long rayg = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (rayg >= Rr) return;
-    const int ray = (int)(rayg % g.n_rays), b = (int)(rayg / g.n_rays), Ns = g.n_samples;
+    // block = CAM_RAYS consecutive rays of ONE frame (blockIdx.y), 4 waves taking rays in turn; the 12 results are summed
+    // in registers and LDS and leave as 12 atomics per block (one block per 4 rays meant 2 048 atomics per address)
+    __shared__ float cam_red[4][12];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.y, Ns = g.n_samples;
+    float sum_R[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sum_T[3] = {0.f, 0.f, 0.f};
+    const int ray_end = min(g.n_rays, (int)(blockIdx.x + 1) * CAM_RAYS);
+    for (int ray = blockIdx.x * CAM_RAYS + wave; ray < ray_end; ray += 4) {
+    const long rayg = (long)b * g.n_rays + ray;
     const float* Rb = R + b * 9;
     const float* Kb = Kinv + b * 9;
     const float* Tb = T + b * 3;
@@ -370,22 +375,34 @@ __global__ void train_camera_bwd_kernel(N3dtGeom g, const float* __restrict__ xy
         g_l += __shfl_xor(g_l, off, 64);
         g_tz += __shfl_xor(g_tz, off, 64);
     }
-    if (lane == 0) {
+    {
         const float gl = g_l + g_dl[0] * dh[0] + g_dl[1] * dh[1] + g_dl[2] * dh[2];
         float g_dh[3] = {g_dl[0] * l, g_dl[1] * l, g_dl[2] * l + gl * l * l};
         const float dot = g_dh[0] * dh[0] + g_dh[1] * dh[1] + g_dh[2] * dh[2];
-        float g_w[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) g_w[d] = (g_dh[d] - dh[d] * dot) / n;
-        if (d_R)
+        for (int i = 0; i < 3; ++i) {
+            const float gw = (g_dh[i] - dh[i] * dot) / n;
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) sum_R[i * 3 + j] += gw * c[j];
+        }
+        sum_T[0] += g_T[0];
+        sum_T[1] += g_T[1];
+        sum_T[2] += g_T[2] + g_tz;
+    }
+    }  // rays of this wave
+    if (lane == 0) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) atomicAdd(&d_R[b * 9 + i * 3 + j], g_w[i] * c[j]);
-        if (d_T) {
-            atomicAdd(&d_T[b * 3 + 0], g_T[0]);
-            atomicAdd(&d_T[b * 3 + 1], g_T[1]);
-            atomicAdd(&d_T[b * 3 + 2], g_T[2] + g_tz);
+        for (int i = 0; i < 9; ++i) cam_red[wave][i] = sum_R[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cam_red[wave][9 + i] = sum_T[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const float v = (cam_red[0][threadIdx.x] + cam_red[1][threadIdx.x]) + (cam_red[2][threadIdx.x] + cam_red[3][threadIdx.x]);
+        if (threadIdx.x < 9) {
+            if (d_R) atomicAdd(&d_R[b * 9 + threadIdx.x], v);
+        } else if (d_T) {
+            atomicAdd(&d_T[b * 3 + threadIdx.x - 9], v);
         }
     }
 }
@@ -667,7 +684,7 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
             n3dt_gemm32(q, s);
             if (d_R) (void)hipMemsetAsync(d_R, 0, sizeof(float) * 9 * B, s);
             if (d_T) (void)hipMemsetAsync(d_T, 0, sizeof(float) * 3 * B, s);
-            hipLaunchKernelGGL(train_camera_bwd_kernel, dim3((unsigned)((Rr + 3) / 4)), dim3(256), 0, s, *g, xy, Rm, Tv, Kinv, t_rand, cat5,
+            hipLaunchKernelGGL(train_camera_bwd_kernel, dim3((g->n_rays + CAM_RAYS - 1) / CAM_RAYS, B), dim3(256), 0, s, *g, xy, Rm, Tv, Kinv, t_rand, cat5,
                                ws + wl.dpe, dxr, d_R, d_T);
         }
         if (l == 0) break;
