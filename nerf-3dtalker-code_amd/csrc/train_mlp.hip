@@ -408,47 +408,55 @@ __global__ void train_camera_bwd_kernel(N3dtGeom g, const float* __restrict__ xy
 }
 
 // out[f][n] += sum over the rows of frame f of X[m][n]   (bias gradients; per frame for the folded biases).
-// One thread = 4 adjacent columns x a 256-row chunk, 8 independent float4 loads in flight; grid (row chunks, frames).
-#define CS_ROWS 256
-__global__ void train_colsum_kernel(const float* __restrict__ X, long ldx, int rows_per_frame, int N, float* __restrict__ out,
-                                    long ldo) {
-    const int n4 = (N + 3) / 4;
-    const int t = threadIdx.x;
-    if (t >= n4) return;
+// 256 threads = ceil(N/4) column groups x row lanes, 8 independent float4 loads in flight per thread, an LDS reduction over
+// the row lanes, then N atomics per workgroup; grid (row chunks, frames) with about 384 chunks in total -- every workgroup's
+// atomics hit the same N addresses, and thousands of those serialise.
+__global__ __launch_bounds__(256) void train_colsum_kernel(const float* __restrict__ X, long ldx, int rows_per_frame, int N,
+                                                           float* __restrict__ out, long ldo, int chunk) {
+    __shared__ f32x4 red[256];
+    const int cg = (N + 3) / 4, lanes = 256 / cg;
+    const int t = threadIdx.x, cq = t % cg, rl = t / cg;
     const int f = blockIdx.y;
-    const int r0 = blockIdx.x * CS_ROWS, r1 = min(rows_per_frame, r0 + CS_ROWS);
-    const float* base = X + ((size_t)f * rows_per_frame) * ldx + 4 * t;
-    const bool vec = (4 * t + 4 <= N) && ((ldx & 3) == 0) && ((((size_t)base) & 15) == 0);
+    const int r0 = blockIdx.x * chunk, r1 = min(rows_per_frame, r0 + chunk);
+    const float* base = X + ((size_t)f * rows_per_frame) * ldx + 4 * cq;
+    const bool vec = (4 * cq + 4 <= N) && ((ldx & 3) == 0) && ((((size_t)base) & 15) == 0);
     f32x4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (vec) {
-        int r = r0;
-        for (; r + 8 <= r1; r += 8) {
-            f32x4 v[8];
+    if (rl < lanes) {
+        int r = r0 + rl;
+        if (vec) {
+            for (; r + 7 * lanes < r1; r += 8 * lanes) {
+                f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (size_t)(r + u) * ldx);
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (size_t)(r + u * lanes) * ldx);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u & 3] += v[u];
+                for (int u = 0; u < 8; ++u) acc[u & 3] += v[u];
+            }
+            for (; r < r1; r += lanes) acc[0] += *reinterpret_cast<const f32x4*>(base + (size_t)r * ldx);
+        } else {
+            for (; r < r1; r += lanes)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * cq + j < N) acc[0][j] += base[(size_t)r * ldx + j];
         }
-        for (; r < r1; ++r) acc[0] += *reinterpret_cast<const f32x4*>(base + (size_t)r * ldx);
-    } else {
-        for (int r = r0; r < r1; ++r)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (4 * t + j < N) acc[0][j] += base[(size_t)r * ldx + j];
     }
-    const f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    red[t] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (t < cg) {
+        f32x4 s = red[t];
+        for (int l = 1; l < lanes; ++l) s += red[l * cg + t];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (4 * t + j < N) atomicAdd(&out[(size_t)f * ldo + 4 * t + j], s[j]);
+        for (int j = 0; j < 4; ++j)
+            if (4 * t + j < N) atomicAdd(&out[(size_t)f * ldo + 4 * t + j], s[j]);
+    }
 }
 
 static void launch_colsum(const float* X, long ldx, int rows_per_frame, int frames, int N, float* out, long ldo, hipStream_t s) {
-    const int n4 = (N + 3) / 4;
-    const int threads = ((n4 + 63) / 64) * 64;
-    hipLaunchKernelGGL(train_colsum_kernel, dim3((rows_per_frame + CS_ROWS - 1) / CS_ROWS, frames), dim3(threads), 0, s, X, ldx,
-                       rows_per_frame, N, out, ldo);
+    int chunk = (int)(((long)rows_per_frame * frames + 383) / 384);
+    if (chunk < 256) chunk = 256;
+    hipLaunchKernelGGL(train_colsum_kernel, dim3((rows_per_frame + chunk - 1) / chunk, frames), dim3(256), 0, s, X, ldx, rows_per_frame, N,
+                       out, ldo, chunk);
 }
 
 // latent folding backward.  dfold[f] holds d b0'[384] (offset 0), d b5' (offset 5*384), d brgb1' (offset of stage 10).
