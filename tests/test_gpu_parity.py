@@ -191,6 +191,22 @@ def test_many_samples_per_ray_against_oracle(precision):
     np.testing.assert_allclose(w.sum(-1) + f["bg_alpha"].cpu().numpy(), 1.0, atol=1e-4 if precision == "fp32" else 5e-3)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_non_power_of_two_feature_map_against_oracle(precision):
+    """featmap_size 12 -> 48^2: the renderer's index math takes its general (division) path instead of shifts and masks,
+    and the ray count is not a multiple of the kernels' tile sizes."""
+    from n3dt import BaseOptions, synthetic as syn
+    from oracle import oracle as orc
+    opt = BaseOptions({"featmap_size": 12, "featmap_nc": 256, "pred_img_size": 48, "num_sample_coarse": 24})
+    sd = syn.make_state_dict(opt, seed=9, bg_noise=0.2)
+    inp = syn.frame_inputs(opt, 3, yaw_range=0.4, first_frame=11)
+    ref = orc.forward(sd, opt, inp, None)
+    net = build_net(opt, sd, precision)
+    out = fwd(net, to_dev(inp), "test", None)
+    assert np.abs(out["merge_img"].cpu().numpy() - ref["merge_img"]).max() <= RGB_TOL[precision]
+    assert np.abs(out["bg_img"].cpu().numpy() - ref["bg_img"]).max() <= RGB_TOL[precision]
+
+
 def test_properties_at_full_size():
     """BASELINE full size (fs 64, 64 samples, B=8): size-independent properties instead of a stored answer."""
     from n3dt import BaseOptions, synthetic as syn
