@@ -252,3 +252,45 @@ def test_fused_bf16_camera_gradients_against_the_fp32_path():
             a, b = g32[k].double().flatten(), g16[k].double().flatten()
             assert float((a - b).abs().max()) <= (0.05 if k == "shape_code" else 0.35) * float(a.abs().max()), (k, fs)
             assert float((a * b).sum() / (a.norm() * b.norm() + 1e-30)) >= 0.98, (k, fs)
+
+
+def test_renderer_gradients_at_a_non_power_of_two_map_are_directional_derivatives():
+    """featmap_size 12 -> 48^2 sends the neural renderer's training kernels through their general (division) index
+    path.  With everything else frozen, the gradient of the loss with respect to the renderer's parameters must match a
+    central finite difference along a random direction (the renderer is smooth apart from LeakyReLU kinks)."""
+    from n3dt import HeadNeRFNet, BaseOptions, synthetic as syn
+    from n3dt.train import data_losses, disk_mask
+    opt = BaseOptions({"featmap_size": 12, "featmap_nc": 256, "pred_img_size": 48, "num_sample_coarse": 16})
+    sd = syn.make_state_dict(opt, seed=3, bg_noise=0.1)
+    net = HeadNeRFNet(opt, False, False).to(dev())
+    net.load_state_dict(sd)
+    B = 2
+    d = {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in syn.frame_inputs(opt, B).items()}
+    mask = disk_mask(B, opt.pred_img_size).to(dev())
+
+    def loss():
+        out = net("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+                  d["batch_Tvecs"], d["batch_inv_inmats"])["coarse_dict"]
+        t = data_losses(out, torch.full_like(out["merge_img"], 0.5), mask)
+        return t["bg_loss"] + t["head_loss"] + t["nonhead_loss"]
+
+    params = [p for n, p in net.named_parameters() if n.startswith("neural_render") and p.requires_grad]
+    for p in net.parameters():
+        p.requires_grad_(False)
+    for p in params:
+        p.requires_grad_(True)
+    loss().backward()
+    gen = torch.Generator().manual_seed(1)
+    dirs = [torch.randn(p.shape, generator=gen).to(dev()) * p.detach().abs().mean() for p in params]
+    analytic = sum(float((p.grad * u).sum()) for p, u in zip(params, dirs))
+    h = 1e-3
+    vals = []
+    with torch.no_grad():
+        for sgn in (+1.0, -1.0):
+            for p, u in zip(params, dirs):
+                p.add_(sgn * h * u)
+            vals.append(float(loss().double()))
+            for p, u in zip(params, dirs):
+                p.sub_(sgn * h * u)
+    numeric = (vals[0] - vals[1]) / (2 * h)
+    assert abs(numeric - analytic) <= 2e-2 * abs(analytic) + 1e-6, (numeric, analytic)
