@@ -37,6 +37,9 @@ struct Gemm32 {
     int gate_act;
     int accumulate;  // C += result instead of C = result
     int split_k;     // >1: grid.z slices of K, combined with atomicAdd (C must be pre-initialised)
+    // bf16 STORAGE (gemm16 only; the pointers above then address bf16 elements and are passed reinterpret_cast'ed):
+    // the neural renderer's mixed-precision training keeps its maps and their gradients as bf16 in HBM
+    int a16, b16, c16, gate16;
 };
 
 void n3dt_gemm32(const Gemm32& g, hipStream_t stream);

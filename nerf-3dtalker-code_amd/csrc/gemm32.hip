@@ -147,10 +147,50 @@ typedef unsigned short g16_u16x4 __attribute__((ext_vector_type(4)));
 #define H_LD (H_BK + 8)
 
 __device__ __forceinline__ unsigned short g16_cvt(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+__device__ __forceinline__ float g16_up(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
 
 // stage a [128 rows x 32 k] operand tile into LDS as T[row][k] (k contiguous), converting to bf16
-__device__ __forceinline__ void g16_stage(unsigned short* T, const float* __restrict__ P, long ld, int kmajor, int row0, int nrows,
-                                          int k0, int kend, int tid) {
+__device__ __forceinline__ void g16_stage(unsigned short* T, const float* __restrict__ P, int is16, long ld, int kmajor, int row0,
+                                          int nrows, int k0, int kend, int tid) {
+    if (is16) {
+        // bf16 storage: the same index maps, 8-byte loads, no conversion
+        const unsigned short* P16 = reinterpret_cast<const unsigned short*>(P);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            g16_u16x4 o = {0, 0, 0, 0};
+            if (!kmajor) {
+                const int idx = tid + 256 * i, row = idx >> 3, kq = (idx & 7) * 4;
+                const int r = row0 + row;
+                if (r < nrows) {
+                    const unsigned short* src = P16 + (long)r * ld + k0 + kq;
+                    if (k0 + kq + 4 <= kend && ((((size_t)src) & 7) == 0)) {
+                        o = *reinterpret_cast<const g16_u16x4*>(src);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (k0 + kq + j < kend) o[j] = src[j];
+                    }
+                }
+                *reinterpret_cast<g16_u16x4*>(T + row * H_LD + kq) = o;
+            } else {
+                const int idx = tid + 256 * i, kr = idx >> 5, c4 = (idx & 31) * 4;
+                const int k = k0 + kr;
+                if (k < kend) {
+                    const unsigned short* src = P16 + (long)k * ld + row0 + c4;
+                    if (row0 + c4 + 4 <= nrows && ((((size_t)src) & 7) == 0)) {
+                        o = *reinterpret_cast<const g16_u16x4*>(src);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (row0 + c4 + j < nrows) o[j] = src[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) T[(c4 + j) * H_LD + kr] = o[j];
+            }
+        }
+        return;
+    }
     if (!kmajor) {
         // memory rows are K-contiguous: thread -> 4 x (row, 4 consecutive k)
 #pragma unroll
@@ -218,8 +258,8 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm32 g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     for (int k0 = kbeg; k0 < kend; k0 += H_BK) {
         __syncthreads();
-        g16_stage(As, g.A, g.lda, g.a_kmajor, m0, g.M, k0, kend, tid);
-        g16_stage(Bs, g.B, g.ldb, g.b_kmajor, n0, g.N, k0, kend, tid);
+        g16_stage(As, g.A, g.a16, g.lda, g.a_kmajor, m0, g.M, k0, kend, tid);
+        g16_stage(Bs, g.B, g.b16, g.ldb, g.b_kmajor, n0, g.N, k0, kend, tid);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < H_BK / 16; ++ks) {
@@ -253,14 +293,21 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm32 g) {
                 if (g.act == G32_ACT_RELU) v = fmaxf(v, 0.0f);
                 else if (g.act == G32_ACT_LRELU) v = v > 0.0f ? v : 0.2f * v;
                 if (g.gate_act != G32_ACT_NONE) {
-                    const float y = g.gate[(long)m * g.ldgate + n];
+                    const float y = g.gate16 ? g16_up(reinterpret_cast<const unsigned short*>(g.gate)[(long)m * g.ldgate + n])
+                                             : g.gate[(long)m * g.ldgate + n];
                     if (g.gate_act == G32_ACT_RELU) v = y > 0.0f ? v : 0.0f;
                     else v = y > 0.0f ? v : 0.2f * v;
                 }
-                float* dst = g.C + (long)m * g.ldc + n;
-                if (g.split_k > 1) atomicAdd(dst, v);
-                else if (g.accumulate) *dst += v;
-                else *dst = v;
+                if (g.c16) {  // bf16 output (never split: a split product is a parameter gradient, fp32)
+                    unsigned short* dst = reinterpret_cast<unsigned short*>(g.C) + (long)m * g.ldc + n;
+                    if (g.accumulate) v += g16_up(*dst);
+                    *dst = g16_cvt(v);
+                } else {
+                    float* dst = g.C + (long)m * g.ldc + n;
+                    if (g.split_k > 1) atomicAdd(dst, v);
+                    else if (g.accumulate) *dst += v;
+                    else *dst = v;
+                }
             }
     }
 }

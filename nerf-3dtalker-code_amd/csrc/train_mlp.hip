@@ -535,6 +535,7 @@ static Gemm32 mk(int M, int N, int K, const float* A, long lda, int ak, const fl
     g.act = G32_ACT_NONE;
     g.gate = nullptr; g.ldgate = 0; g.gate_act = G32_ACT_NONE;
     g.accumulate = 0; g.split_k = 1;
+    g.a16 = g.b16 = g.c16 = g.gate16 = 0;
     return g;
 }
 

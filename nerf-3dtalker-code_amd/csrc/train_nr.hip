@@ -62,10 +62,38 @@ extern "C" size_t n3dt_nr_train_ws_floats(const N3dtGeom* g, int nb) { return nr
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
+// Storage element of the feature maps and of their gradients: float (the exact path) or bf16 (the mixed-precision
+// path: bf16 maps in HBM, fp32 arithmetic in registers, fp32 parameters and parameter gradients).  The kernels below are
+// written once against these load / store helpers.
+struct nrt_bf16 {
+    unsigned short u;
+};
+typedef unsigned short nrt_u16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float nrt_ld(const float* p) { return *p; }
+__device__ __forceinline__ float nrt_ld(const nrt_bf16* p) { return __builtin_bit_cast(float, (unsigned)p->u << 16); }
+__device__ __forceinline__ void nrt_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void nrt_st(nrt_bf16* p, float v) { p->u = __builtin_bit_cast(unsigned short, (__bf16)v); }
+__device__ __forceinline__ f32x4 nrt_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 nrt_ld4(const nrt_bf16* p) {
+    const nrt_u16x4 u = *reinterpret_cast<const nrt_u16x4*>(p);
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_bit_cast(float, (unsigned)u[j] << 16);
+    return v;
+}
+__device__ __forceinline__ void nrt_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void nrt_st4(nrt_bf16* p, f32x4 v) {
+    nrt_u16x4 u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[j] = __builtin_bit_cast(unsigned short, (__bf16)v[j]);
+    *reinterpret_cast<nrt_u16x4*>(p) = u;
+}
+
 // ---- forward pieces ---------------------------------------------------------------------------
 // tv [M][4C] (+ residual x.repeat) -> pixel-shuffled ps [4M][C]   (PixelShuffleUpsample.py:36,41-42)
-__global__ void nrt_shuffle_kernel(int nb, int H, int W, int C, const float* __restrict__ tv, const float* __restrict__ x,
-                                   float* __restrict__ ps) {
+template <class T, class TX>
+__global__ void nrt_shuffle_kernel(int nb, int H, int W, int C, const T* __restrict__ tv, const TX* __restrict__ x,
+                                   T* __restrict__ ps) {
     // thread = 4 adjacent output channels of one output pixel (one 16-byte store)
     const int c4 = C >> 2;
     const size_t total = (size_t)nb * H * W * 4 * c4;
@@ -78,18 +106,19 @@ __global__ void nrt_shuffle_kernel(int nb, int H, int W, int C, const float* __r
     const int ow = n3dt_rem(opix, dW2), oh = n3dt_rem(orow, dH2), img = (int)n3dt_quot(orow, dH2);
     const int h = oh >> 1, di = oh & 1, w = ow >> 1, dj = ow & 1;
     const size_t m = ((size_t)img * H + h) * W + w;
-    const float* tr = tv + m * 4 * C;
-    const float* xr = x + m * C;
+    const T* tr = tv + m * 4 * C;
+    const TX* xr = x + m * C;
     f32x4 out;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int o = 4 * (c + j) + 2 * di + dj;  // pixel_shuffle source channel; x.repeat(1,4,1,1) adds x[o % C]
-        out[j] = tr[o] + xr[n3dt_rem(o, dC)];
+        out[j] = nrt_ld(tr + o) + nrt_ld(xr + n3dt_rem(o, dC));
     }
-    *reinterpret_cast<f32x4*>(ps + opix * C + c) = out;
+    nrt_st4(ps + opix * C + c, out);
 }
 
-__global__ void nrt_blur_kernel(int nb, int H, int W, int C, const float* __restrict__ x, float* __restrict__ y) {
+template <class T>
+__global__ void nrt_blur_kernel(int nb, int H, int W, int C, const T* __restrict__ x, T* __restrict__ y) {
     const int c4 = C / 4;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)nb * H * W * c4) return;
@@ -105,14 +134,15 @@ __global__ void nrt_blur_kernel(int nb, int H, int W, int C, const float* __rest
 #pragma unroll
         for (int dj = -1; dj <= 1; ++dj) {
             int hh = reflect1(h + di, H), ww = reflect1(w + dj, W);
-            f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)img * H + hh) * W + ww) * C + 4 * cq);
+            f32x4 v = nrt_ld4(x + (((size_t)img * H + hh) * W + ww) * C + 4 * cq);
             acc += (k[di + 1] * k[dj + 1]) * v;
         }
-    *reinterpret_cast<f32x4*>(y + pix * C + 4 * cq) = acc;
+    nrt_st4(y + pix * C + 4 * cq, acc);
 }
 
 // planar rgb [nb,3,HW] (+)= W[3][K] net[pix][K] + b     (feat_2_rgb_list)
-__global__ void nrt_to_rgb_kernel(int nb, int HW, int K, const float* __restrict__ net, const float* __restrict__ Wt,
+template <class T>
+__global__ void nrt_to_rgb_kernel(int nb, int HW, int K, const T* __restrict__ net, const float* __restrict__ Wt,
                                   const float* __restrict__ bias, const float* __restrict__ rgb_in, float* __restrict__ rgb_out,
                                   int final_sigmoid) {
     extern __shared__ float wl[];
@@ -120,10 +150,10 @@ __global__ void nrt_to_rgb_kernel(int nb, int HW, int K, const float* __restrict
     __syncthreads();
     size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= (size_t)nb * HW) return;
-    const float* xr = net + pix * K;
+    const T* xr = net + pix * K;
     float a0 = bias[0], a1 = bias[1], a2 = bias[2];
     for (int k = 0; k < K; ++k) {
-        const float v = xr[k];
+        const float v = nrt_ld(xr + k);
         a0 = fmaf(wl[k], v, a0);
         a1 = fmaf(wl[K + k], v, a1);
         a2 = fmaf(wl[2 * K + k], v, a2);
@@ -184,7 +214,8 @@ __device__ __forceinline__ void blur_adj_w3(int j, int n, float (&w)[3]) {
     w[2] = j + 1 < n ? (j == n - 2 ? 0.5f : 0.25f) : 0.0f;    // from output j+1 (+ output n-1's reflected read when j == n-2)
 }
 
-__global__ void nrt_blur_adj_kernel(int nb, int H, int W, int C, const float* __restrict__ dy, float* __restrict__ dx) {
+template <class T>
+__global__ void nrt_blur_adj_kernel(int nb, int H, int W, int C, const T* __restrict__ dy, T* __restrict__ dx) {
     const int c4 = C / 4;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)nb * H * W * c4) return;
@@ -203,11 +234,11 @@ __global__ void nrt_blur_adj_kernel(int nb, int H, int W, int C, const float* __
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
             const int wc = min(max(w + b - 1, 0), W - 1);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(dy + (((size_t)img * H + hh) * W + wc) * C + 4 * cq);
+            const f32x4 v = nrt_ld4(dy + (((size_t)img * H + hh) * W + wc) * C + 4 * cq);
             acc += (wh[a] * ww[b]) * v;
         }
     }
-    *reinterpret_cast<f32x4*>(dx + pix * C + 4 * cq) = acc;
+    nrt_st4(dx + pix * C + 4 * cq, acc);
 }
 
 // planar variant for the rgb pyramid (single channel planes)
@@ -266,8 +297,9 @@ __global__ void nrt_sigmoid_bwd_kernel(size_t n, const float* __restrict__ y, co
 }
 
 // dnet[pix][k] (+)= sum_c d_rgb[img][c][p] W[c][k], gated by lrelu'(net) when gate != nullptr
+template <class T>
 __global__ void nrt_to_rgb_bwd_kernel(int nb, int HW, int K, const float* __restrict__ d_rgb, const float* __restrict__ Wt,
-                                      const float* __restrict__ gate, float* __restrict__ dnet, int accumulate) {
+                                      const T* __restrict__ gate, T* __restrict__ dnet, int accumulate) {
     extern __shared__ float wl[];
     for (int i = threadIdx.x; i < 3 * K; i += blockDim.x) wl[i] = Wt[i];
     __syncthreads();
@@ -281,25 +313,30 @@ __global__ void nrt_to_rgb_bwd_kernel(int nb, int HW, int K, const float* __rest
     f32x4 v;
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = d0 * wl[4 * kq + j] + d1 * wl[K + 4 * kq + j] + d2 * wl[2 * K + 4 * kq + j];
-    float* dst = dnet + pix * K + 4 * kq;
+    T* dst = dnet + pix * K + 4 * kq;
     if (gate) {
-        f32x4 y = *reinterpret_cast<const f32x4*>(gate + pix * K + 4 * kq);
+        f32x4 y = nrt_ld4(gate + pix * K + 4 * kq);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = y[j] > 0.0f ? v[j] : 0.2f * v[j];
     }
-    if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
-    *reinterpret_cast<f32x4*>(dst) = v;
+    if (accumulate) v += nrt_ld4(dst);
+    nrt_st4(dst, v);
 }
 
 // x *= lrelu'(gate)
-__global__ void nrt_gate_kernel(size_t n, const float* __restrict__ gate, float* __restrict__ x) {
+template <class T>
+__global__ void nrt_gate_kernel(size_t n, const T* __restrict__ gate, T* __restrict__ x) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] = gate[i] > 0.0f ? x[i] : 0.2f * x[i];
+    if (i < n) {
+        const float v = nrt_ld(x + i);
+        nrt_st(x + i, nrt_ld(gate + i) > 0.0f ? v : 0.2f * v);
+    }
 }
 
 // pixel-shuffle + residual adjoint: dps [4M][C] -> dtv [M][4C] gated by lrelu'(tv), and dx_res[M][C] = sum over the 4 repeats
-__global__ void nrt_unshuffle_kernel(int nb, int H, int W, int C, const float* __restrict__ dps, const float* __restrict__ tv,
-                                     float* __restrict__ dtv, float* __restrict__ dxres) {
+template <class T>
+__global__ void nrt_unshuffle_kernel(int nb, int H, int W, int C, const T* __restrict__ dps, const T* __restrict__ tv,
+                                     T* __restrict__ dtv, T* __restrict__ dxres) {
     const size_t total = (size_t)nb * H * W * C;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -313,29 +350,25 @@ __global__ void nrt_unshuffle_kernel(int nb, int H, int W, int C, const float* _
     for (int r = 0; r < 4; ++r) {
         const int o = r * C + cp;
         const int c = o >> 2, di = (o >> 1) & 1, dj = o & 1;
-        const float d = dps[(((size_t)img * 2 * H + 2 * h + di) * 2 * W + 2 * w + dj) * C + c];
+        const float d = nrt_ld(dps + (((size_t)img * 2 * H + 2 * h + di) * 2 * W + 2 * w + dj) * C + c);
         res += d;
-        const float y = tv[m * 4 * C + o];
-        dtv[m * 4 * C + o] = y > 0.0f ? d : 0.2f * d;
+        const float y = nrt_ld(tv + m * 4 * C + o);
+        nrt_st(dtv + m * 4 * C + o, y > 0.0f ? d : 0.2f * d);
     }
-    dxres[i] = res;
-}
-
-__global__ void nrt_add_kernel(size_t n, const float* __restrict__ a, float* __restrict__ x) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] += a[i];
+    nrt_st(dxres + i, res);
 }
 
 // out[n] += sum_m X[m][n]: one thread = 4 adjacent columns x a 256-row chunk, 8 independent float4 loads in flight
 #define NRT_CS_ROWS 512
-__global__ __launch_bounds__(256) void nrt_colsum_kernel(const float* __restrict__ X, long ldx, long rows, int N, float* __restrict__ out,
+template <class T>
+__global__ __launch_bounds__(256) void nrt_colsum_kernel(const T* __restrict__ X, long ldx, long rows, int N, float* __restrict__ out,
                                                          int chunk) {
     // thread = 4 adjacent columns x one row lane (256 / (N/4) row lanes; every N here is a multiple of 32, <= 1024)
     __shared__ f32x4 red[256];
     const int cg = N >> 2, lanes = 256 / cg;
     const int t = threadIdx.x, cq = t % cg, rl = t / cg;
     const long r0 = (long)blockIdx.x * chunk, r1 = min(rows, r0 + chunk);
-    const float* base = X + 4 * cq;
+    const T* base = X + 4 * cq;
     f32x4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -344,11 +377,11 @@ __global__ __launch_bounds__(256) void nrt_colsum_kernel(const float* __restrict
         for (; r + 7L * lanes < r1; r += 8L * lanes) {
             f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (r + (long)u * lanes) * ldx);
+            for (int u = 0; u < 8; ++u) v[u] = nrt_ld4(base + (r + (long)u * lanes) * ldx);
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc[u & 3] += v[u];
         }
-        for (; r < r1; r += lanes) acc[0] += *reinterpret_cast<const f32x4*>(base + r * ldx);
+        for (; r < r1; r += lanes) acc[0] += nrt_ld4(base + r * ldx);
     }
     red[t] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     __syncthreads();
@@ -359,13 +392,14 @@ __global__ __launch_bounds__(256) void nrt_colsum_kernel(const float* __restrict
         for (int j = 0; j < 4; ++j) atomicAdd(&out[4 * t + j], sum[j]);
     }
 }
-static void launch_nrt_colsum(const float* X, long ldx, long rows, int N, float* out, hipStream_t s) {
+template <class T>
+static void launch_nrt_colsum(const T* X, long ldx, long rows, int N, float* out, hipStream_t s) {
     // about 384 workgroups: every workgroup ends in N atomics on the SAME N addresses, and thousands of same-address atomics
     // serialise (they, not the loads, set the time of the 1536-workgroup version)
     long chunk = (rows + 383) / 384;
     if (chunk < NRT_CS_ROWS) chunk = NRT_CS_ROWS;
     chunk = (chunk + 31) / 32 * 32;
-    hipLaunchKernelGGL(nrt_colsum_kernel, dim3((unsigned)((rows + chunk - 1) / chunk)), dim3(256), 0, s, X, ldx, rows, N, out, (int)chunk);
+    hipLaunchKernelGGL(nrt_colsum_kernel<T>, dim3((unsigned)((rows + chunk - 1) / chunk)), dim3(256), 0, s, X, ldx, rows, N, out, (int)chunk);
 }
 
 // db[c] += sum over images and pixels of planar d_rgb
@@ -390,8 +424,9 @@ __global__ void nrt_rgb_bias_kernel(int nb, int HW, const float* __restrict__ d_
 // (a 3 x co result over up to 10^6 pixels: a reduction, not a GEMM).  Thread = 4 adjacent channels x one pixel lane;
 // block = NRT_WG_PIX consecutive pixels of one image; co in {32, 64, 128, 256}.
 #define NRT_WG_PIX 512
+template <class T>
 __global__ __launch_bounds__(256) void nrt_to_rgb_wgrad_kernel(int HW, int co, const float* __restrict__ d_rgb,
-                                                               const float* __restrict__ net, float* __restrict__ dW) {
+                                                               const T* __restrict__ net, float* __restrict__ dW) {
     __shared__ float red[256][13];
     const int cg = co >> 2, lanes = 256 / cg;
     const int t = threadIdx.x, c4 = (t % cg) * 4, pl = t / cg;
@@ -399,7 +434,7 @@ __global__ __launch_bounds__(256) void nrt_to_rgb_wgrad_kernel(int HW, int co, c
     const int img = blockIdx.x / chunks, p0 = (blockIdx.x % chunks) * NRT_WG_PIX;
     const int p1 = min(HW, p0 + NRT_WG_PIX);
     const float* d = d_rgb + (size_t)img * 3 * HW;
-    const float* x = net + (size_t)img * HW * co + c4;
+    const T* x = net + (size_t)img * HW * co + c4;
     float acc[3][4];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -422,7 +457,7 @@ __global__ __launch_bounds__(256) void nrt_to_rgb_wgrad_kernel(int HW, int co, c
         float gg[4][3];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            v[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(p + u * lanes) * co);
+            v[u] = nrt_ld4(x + (size_t)(p + u * lanes) * co);
 #pragma unroll
             for (int k = 0; k < 3; ++k) gg[u][k] = d[(size_t)k * HW + p + u * lanes];
         }
@@ -430,7 +465,7 @@ __global__ __launch_bounds__(256) void nrt_to_rgb_wgrad_kernel(int HW, int co, c
         for (int u = 0; u < 4; ++u) one(p, v[u], gg[u][0], gg[u][1], gg[u][2]);
     }
     for (; p < p1; p += lanes)
-        one(p, *reinterpret_cast<const f32x4*>(x + (size_t)p * co), d[p], d[(size_t)HW + p], d[(size_t)2 * HW + p]);
+        one(p, nrt_ld4(x + (size_t)p * co), d[p], d[(size_t)HW + p], d[(size_t)2 * HW + p]);
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -444,9 +479,10 @@ __global__ __launch_bounds__(256) void nrt_to_rgb_wgrad_kernel(int HW, int co, c
         atomicAdd(&dW[(size_t)k * co + c], sum);
     }
 }
-static void launch_to_rgb_wgrad(int nb, int HW, int co, const float* d_rgb, const float* net, float* dW, hipStream_t s) {
+template <class T>
+static void launch_to_rgb_wgrad(int nb, int HW, int co, const float* d_rgb, const T* net, float* dW, hipStream_t s) {
     const int chunks = (HW + NRT_WG_PIX - 1) / NRT_WG_PIX;
-    hipLaunchKernelGGL(nrt_to_rgb_wgrad_kernel, dim3(nb * chunks), dim3(256), 0, s, HW, co, d_rgb, net, dW);
+    hipLaunchKernelGGL(nrt_to_rgb_wgrad_kernel<T>, dim3(nb * chunks), dim3(256), 0, s, HW, co, d_rgb, net, dW);
 }
 
 #define GRID1(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256)
@@ -461,6 +497,7 @@ static Gemm32 mk(int M, int N, int K, const float* A, long lda, int ak, const fl
     g.act = G32_ACT_NONE;
     g.gate = nullptr; g.ldgate = 0; g.gate_act = G32_ACT_NONE;
     g.accumulate = 0; g.split_k = 1;
+    g.a16 = g.b16 = g.c16 = g.gate16 = 0;
     return g;
 }
 // parameter-gradient products always ADD into their destination: atomics when K is split, += otherwise.
@@ -474,111 +511,157 @@ static void set_grad_split(Gemm32& q, long K) {
     q.accumulate = q.split_k <= 1 ? 1 : 0;
 }
 
-// featmap [nb][fs*fs][C] -> img [nb,3,P,P]; all intermediates kept in `saved`
-extern "C" void n3dt_launch_nr_train_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap, float* img,
-                                         float* saved, float* ws, int bf16, hipStream_t s) {
+// bf16-storage GEMM operands travel through the descriptor's float pointers (gemm32.h)
+template <class T>
+static inline const float* as_f(const T* p) { return reinterpret_cast<const float*>(p); }
+template <class T>
+static inline float* as_f(T* p) { return reinterpret_cast<float*>(p); }
+template <class T>
+static constexpr int is16() { return sizeof(T) == 2 ? 1 : 0; }
+
+// to fp32 at the boundary (d_featmap is fp32 in both modes)
+template <class T>
+__global__ void nrt_to_f32_kernel(size_t n, const T* __restrict__ x, float* __restrict__ y) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = nrt_ld(x + i);
+}
+
+// featmap [nb][fs*fs][C] -> img [nb,3,P,P]; all intermediates kept in `saved`.
+// T = storage of the maps (float: exact path, every product on the fp32 MFMA GEMM; nrt_bf16: mixed precision, bf16 maps and
+// bf16 MFMA products).  The layouts count ELEMENTS, so the bf16 path addresses the same offsets on 2-byte elements and
+// simply leaves the upper half of the float-sized buffers unused; the planar fp32 regions (img, rgb pyramid) keep their
+// float offsets, which lie beyond every bf16 region.
+template <class T>
+static void nr_train_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap, float* img, float* saved_f,
+                         float* ws_f, hipStream_t s) {
+    constexpr int h16 = is16<T>();
     const NrSaved sv = nr_saved_layout(g, nb);
     const NrWs wl = nr_ws_layout(g, nb);
     const int C = g->feat_nc, nblk = g->n_blocks;
-    float* rgbA = ws + wl.rgb0;
-    float* rgbB = ws + wl.rgb1;
-    float* ps = ws + wl.a;
+    T* saved = reinterpret_cast<T*>(saved_f);
+    T* ws = reinterpret_cast<T*>(ws_f);
+    float* rgbA = ws_f + wl.rgb0;
+    float* rgbB = ws_f + wl.rgb1;
+    float* img_saved = saved_f + sv.img;
+    T* ps = ws + wl.a;
     int h = g->featmap_size;
-    hipLaunchKernelGGL(nrt_to_rgb_kernel, GRID1((size_t)nb * h * h), 3 * C * sizeof(float), s, nb, h * h, C, featmap, p->to_rgb_w[0],
+    hipLaunchKernelGGL(nrt_to_rgb_kernel<float>, GRID1((size_t)nb * h * h), 3 * C * sizeof(float), s, nb, h * h, C, featmap, p->to_rgb_w[0],
                        p->to_rgb_b[0], (const float*)nullptr, rgbB, 0);
     hipLaunchKernelGGL(nrt_rgb_up_kernel, GRID1((size_t)nb * 3 * 4 * h * h), 0, s, nb * 3, h, h, rgbB, rgbA);
-    const float* x = featmap;
+    const T* x = nullptr;  // level 0 reads the fp32 featmap
     for (int i = 0; i < nblk; ++i) {
         const int ci = nr_ch(C, i), co = nr_ch(C, i + 1), M = nb * h * h;
-        Gemm32 q1 = mk(M, 2 * ci, ci, x, ci, 0, p->psu1_w[i], ci, 0, saved + sv.t1[i], 2 * ci);
+        Gemm32 q1 = mk(M, 2 * ci, ci, i == 0 ? featmap : as_f(x), ci, 0, p->psu1_w[i], ci, 0, as_f(saved + sv.t1[i]), 2 * ci);
         q1.bias = p->psu1_b[i]; q1.act = G32_ACT_LRELU;
-        n3dt_gemm(q1, bf16, s);
-        Gemm32 q2 = mk(M, 4 * ci, 2 * ci, saved + sv.t1[i], 2 * ci, 0, p->psu2_w[i], 2 * ci, 0, saved + sv.tv[i], 4 * ci);
+        q1.a16 = i == 0 ? 0 : h16; q1.c16 = h16;
+        n3dt_gemm(q1, h16, s);
+        Gemm32 q2 = mk(M, 4 * ci, 2 * ci, as_f(saved + sv.t1[i]), 2 * ci, 0, p->psu2_w[i], 2 * ci, 0, as_f(saved + sv.tv[i]), 4 * ci);
         q2.bias = p->psu2_b[i]; q2.act = G32_ACT_LRELU;
-        n3dt_gemm(q2, bf16, s);
-        hipLaunchKernelGGL(nrt_shuffle_kernel, GRID1((size_t)M * ci), 0, s, nb, h, h, ci, saved + sv.tv[i], x, ps);
+        q2.a16 = h16; q2.c16 = h16;
+        n3dt_gemm(q2, h16, s);
+        if (i == 0)
+            hipLaunchKernelGGL((nrt_shuffle_kernel<T, float>), GRID1((size_t)M * ci), 0, s, nb, h, h, ci, (const T*)(saved + sv.tv[i]), featmap, ps);
+        else
+            hipLaunchKernelGGL((nrt_shuffle_kernel<T, T>), GRID1((size_t)M * ci), 0, s, nb, h, h, ci, (const T*)(saved + sv.tv[i]), x, ps);
         h *= 2;
-        hipLaunchKernelGGL(nrt_blur_kernel, GRID1((size_t)nb * h * h * (ci / 4)), 0, s, nb, h, h, ci, ps, saved + sv.bl[i]);
-        Gemm32 q3 = mk(nb * h * h, co, ci, saved + sv.bl[i], ci, 0, p->feat_w[i], ci, 0, saved + sv.net[i], co);
+        hipLaunchKernelGGL(nrt_blur_kernel<T>, GRID1((size_t)nb * h * h * (ci / 4)), 0, s, nb, h, h, ci, (const T*)ps, saved + sv.bl[i]);
+        Gemm32 q3 = mk(nb * h * h, co, ci, as_f(saved + sv.bl[i]), ci, 0, p->feat_w[i], ci, 0, as_f(saved + sv.net[i]), co);
         q3.bias = p->feat_b[i]; q3.act = G32_ACT_LRELU;
-        n3dt_gemm(q3, bf16, s);
+        q3.a16 = h16; q3.c16 = h16;
+        n3dt_gemm(q3, h16, s);
         const bool last = i == nblk - 1;
-        hipLaunchKernelGGL(nrt_to_rgb_kernel, GRID1((size_t)nb * h * h), 3 * co * sizeof(float), s, nb, h * h, co, saved + sv.net[i],
-                           p->to_rgb_w[i + 1], p->to_rgb_b[i + 1], (const float*)rgbA, last ? saved + sv.img : rgbB, last ? 1 : 0);
+        hipLaunchKernelGGL(nrt_to_rgb_kernel<T>, GRID1((size_t)nb * h * h), 3 * co * sizeof(float), s, nb, h * h, co,
+                           (const T*)(saved + sv.net[i]), p->to_rgb_w[i + 1], p->to_rgb_b[i + 1], (const float*)rgbA, last ? img_saved : rgbB,
+                           last ? 1 : 0);
         if (!last) hipLaunchKernelGGL(nrt_rgb_up_kernel, GRID1((size_t)nb * 3 * 4 * h * h), 0, s, nb * 3, h, h, rgbB, rgbA);
         x = saved + sv.net[i];
     }
     const size_t P = (size_t)g->featmap_size << nblk;
-    (void)hipMemcpyAsync(img, saved + sv.img, sizeof(float) * nb * 3 * P * P, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(img, img_saved, sizeof(float) * nb * 3 * P * P, hipMemcpyDeviceToDevice, s);
+}
+
+extern "C" void n3dt_launch_nr_train_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap, float* img,
+                                         float* saved, float* ws, int bf16, hipStream_t s) {
+    if (bf16) nr_train_fwd<nrt_bf16>(g, nb, p, featmap, img, saved, ws, s);
+    else nr_train_fwd<float>(g, nb, p, featmap, img, saved, ws, s);
 }
 
 // gradients are ACCUMULATED into gp (same pointer layout as the parameters); d_featmap is overwritten
-extern "C" void n3dt_launch_nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N3dtRenderGrads* gp,
-                                   const float* featmap, const float* d_img, const float* saved, float* d_featmap, float* ws,
-                                   int bf16, hipStream_t s) {
+template <class T>
+static void nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N3dtRenderGrads* gp, const float* featmap,
+                   const float* d_img, const float* saved_f, float* d_featmap, float* ws_f, hipStream_t s) {
+    constexpr int h16 = is16<T>();
     const NrSaved sv = nr_saved_layout(g, nb);
     const NrWs wl = nr_ws_layout(g, nb);
     const int C = g->feat_nc, nblk = g->n_blocks;
     const size_t P = (size_t)g->featmap_size << nblk;
-    float* bufA = ws + wl.a;
-    float* bufB = ws + wl.b;
-    float* bufC = ws + wl.c;
-    float* drgb = ws + wl.rgb0;   // gradient w.r.t. the running rgb sum at the current resolution
-    float* dtmp = ws + wl.rgb1;
+    const T* saved = reinterpret_cast<const T*>(saved_f);
+    T* ws = reinterpret_cast<T*>(ws_f);
+    T* bufA = ws + wl.a;
+    T* bufB = ws + wl.b;
+    T* bufC = ws + wl.c;
+    float* drgb = ws_f + wl.rgb0;   // gradient w.r.t. the running rgb sum at the current resolution
+    float* dtmp = ws_f + wl.rgb1;
     int h = (int)P;
-    hipLaunchKernelGGL(nrt_sigmoid_bwd_kernel, GRID1((size_t)nb * 3 * P * P), 0, s, (size_t)nb * 3 * P * P, saved + sv.img, d_img, drgb);
-    float* dnet = bufA;  // gradient w.r.t. net_i (stage output), [nb*h*h][co]
+    hipLaunchKernelGGL(nrt_sigmoid_bwd_kernel, GRID1((size_t)nb * 3 * P * P), 0, s, (size_t)nb * 3 * P * P, saved_f + sv.img, d_img, drgb);
+    T* dnet = bufA;  // gradient w.r.t. net_i (stage output), [nb*h*h][co]
     for (int i = nblk - 1; i >= 0; --i) {
         const int ci = nr_ch(C, i), co = nr_ch(C, i + 1);
         const int hin = h / 2, M = nb * hin * hin, M4 = nb * h * h, HW = h * h;
-        const float* x = i == 0 ? featmap : saved + sv.net[i - 1];
-        const float* net = saved + sv.net[i];
+        const T* net = saved + sv.net[i];
         // rgb = rgb_prev_up + feat_2_rgb[i+1](net): parameter grads, then d net (gated by lrelu'(net))
-        launch_to_rgb_wgrad(nb, HW, co, drgb, net, gp->to_rgb_w[i + 1], s);
+        launch_to_rgb_wgrad<T>(nb, HW, co, drgb, net, gp->to_rgb_w[i + 1], s);
         hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[i + 1]);
         // d net: from the rgb branch (+ from the next stage's input gradient, already in dnet when i < nblk-1)
         if (i == nblk - 1) {
-            hipLaunchKernelGGL(nrt_to_rgb_bwd_kernel, GRID1((size_t)M4 * (co / 4)), 3 * co * sizeof(float), s, nb, HW, co, drgb,
+            hipLaunchKernelGGL(nrt_to_rgb_bwd_kernel<T>, GRID1((size_t)M4 * (co / 4)), 3 * co * sizeof(float), s, nb, HW, co, drgb,
                                p->to_rgb_w[i + 1], net, dnet, 0);
         } else {
             // dnet currently holds dL/d(net) from stage i+1 (ungated); add the rgb branch, then gate once
-            hipLaunchKernelGGL(nrt_to_rgb_bwd_kernel, GRID1((size_t)M4 * (co / 4)), 3 * co * sizeof(float), s, nb, HW, co, drgb,
-                               p->to_rgb_w[i + 1], (const float*)nullptr, dnet, 1);
-            hipLaunchKernelGGL(nrt_gate_kernel, GRID1((size_t)M4 * co), 0, s, (size_t)M4 * co, net, dnet);
+            hipLaunchKernelGGL(nrt_to_rgb_bwd_kernel<T>, GRID1((size_t)M4 * (co / 4)), 3 * co * sizeof(float), s, nb, HW, co, drgb,
+                               p->to_rgb_w[i + 1], (const T*)nullptr, dnet, 1);
+            hipLaunchKernelGGL(nrt_gate_kernel<T>, GRID1((size_t)M4 * co), 0, s, (size_t)M4 * co, net, dnet);
         }
         // feat conv: net = lrelu(bl Wf^T + bf)
         {
-            Gemm32 w = mk(co, ci, M4, dnet, co, 1, saved + sv.bl[i], ci, 1, gp->feat_w[i], ci);
+            Gemm32 w = mk(co, ci, M4, as_f(dnet), co, 1, as_f(saved + sv.bl[i]), ci, 1, gp->feat_w[i], ci);
+            w.a16 = h16; w.b16 = h16;
             set_grad_split(w, M4);
-            n3dt_gemm(w, bf16, s);
-            launch_nrt_colsum(dnet, (long)co, (long)M4, co, gp->feat_b[i], s);
-            Gemm32 q = mk(M4, ci, co, dnet, co, 0, p->feat_w[i], ci, 1, bufB, ci);  // d bl
-            n3dt_gemm(q, bf16, s);
+            n3dt_gemm(w, h16, s);
+            launch_nrt_colsum<T>(dnet, (long)co, (long)M4, co, gp->feat_b[i], s);
+            Gemm32 q = mk(M4, ci, co, as_f(dnet), co, 0, p->feat_w[i], ci, 1, as_f(bufB), ci);  // d bl
+            q.a16 = h16; q.c16 = h16;
+            n3dt_gemm(q, h16, s);
         }
         // blur adjoint -> d ps (bufC), then un-shuffle into d tv (bufB, gated) and the residual gradient (bufA)
-        hipLaunchKernelGGL(nrt_blur_adj_kernel, GRID1((size_t)M4 * (ci / 4)), 0, s, nb, h, h, ci, bufB, bufC);
-        hipLaunchKernelGGL(nrt_unshuffle_kernel, GRID1((size_t)M * ci), 0, s, nb, hin, hin, ci, bufC, saved + sv.tv[i], bufB, bufA);
-        float* dtv = bufB;    // [M][4ci]
-        float* dxres = bufA;  // [M][ci]
+        hipLaunchKernelGGL(nrt_blur_adj_kernel<T>, GRID1((size_t)M4 * (ci / 4)), 0, s, nb, h, h, ci, (const T*)bufB, bufC);
+        hipLaunchKernelGGL(nrt_unshuffle_kernel<T>, GRID1((size_t)M * ci), 0, s, nb, hin, hin, ci, (const T*)bufC, saved + sv.tv[i], bufB, bufA);
+        T* dtv = bufB;    // [M][4ci]
+        T* dxres = bufA;  // [M][ci]
         // layer_2: tv = lrelu(t1 W2^T + b2)
         {
-            Gemm32 w = mk(4 * ci, 2 * ci, M, dtv, 4 * ci, 1, saved + sv.t1[i], 2 * ci, 1, gp->psu2_w[i], 2 * ci);
+            Gemm32 w = mk(4 * ci, 2 * ci, M, as_f(dtv), 4 * ci, 1, as_f(saved + sv.t1[i]), 2 * ci, 1, gp->psu2_w[i], 2 * ci);
+            w.a16 = h16; w.b16 = h16;
             set_grad_split(w, M);
-            n3dt_gemm(w, bf16, s);
-            launch_nrt_colsum(dtv, (long)4 * ci, (long)M, 4 * ci, gp->psu2_b[i], s);
-            Gemm32 q = mk(M, 2 * ci, 4 * ci, dtv, 4 * ci, 0, p->psu2_w[i], 2 * ci, 1, bufC, 2 * ci);  // d t1, gated by lrelu'(t1)
-            q.gate = saved + sv.t1[i]; q.ldgate = 2 * ci; q.gate_act = G32_ACT_LRELU;
-            n3dt_gemm(q, bf16, s);
+            n3dt_gemm(w, h16, s);
+            launch_nrt_colsum<T>(dtv, (long)4 * ci, (long)M, 4 * ci, gp->psu2_b[i], s);
+            Gemm32 q = mk(M, 2 * ci, 4 * ci, as_f(dtv), 4 * ci, 0, p->psu2_w[i], 2 * ci, 1, as_f(bufC), 2 * ci);  // d t1, gated by lrelu'(t1)
+            q.gate = as_f(saved + sv.t1[i]); q.ldgate = 2 * ci; q.gate_act = G32_ACT_LRELU;
+            q.a16 = h16; q.c16 = h16; q.gate16 = h16;
+            n3dt_gemm(q, h16, s);
         }
         // layer_1: t1 = lrelu(x W1^T + b1);  dx = dt1 W1 + residual gradient
         {
-            Gemm32 w = mk(2 * ci, ci, M, bufC, 2 * ci, 1, x, ci, 1, gp->psu1_w[i], ci);
+            Gemm32 w = i == 0 ? mk(2 * ci, ci, M, as_f(bufC), 2 * ci, 1, featmap, ci, 1, gp->psu1_w[i], ci)
+                              : mk(2 * ci, ci, M, as_f(bufC), 2 * ci, 1, as_f(saved + sv.net[i - 1]), ci, 1, gp->psu1_w[i], ci);
+            w.a16 = h16; w.b16 = i == 0 ? 0 : h16;
             set_grad_split(w, M);
-            n3dt_gemm(w, bf16, s);
-            launch_nrt_colsum(bufC, (long)2 * ci, (long)M, 2 * ci, gp->psu1_b[i], s);
-            Gemm32 q = mk(M, ci, 2 * ci, bufC, 2 * ci, 0, p->psu1_w[i], ci, 1, dxres, ci);
+            n3dt_gemm(w, h16, s);
+            launch_nrt_colsum<T>(bufC, (long)2 * ci, (long)M, 2 * ci, gp->psu1_b[i], s);
+            Gemm32 q = mk(M, ci, 2 * ci, as_f(bufC), 2 * ci, 0, p->psu1_w[i], ci, 1, as_f(dxres), ci);
             q.accumulate = 1;
-            n3dt_gemm(q, bf16, s);
+            q.a16 = h16; q.c16 = h16;
+            n3dt_gemm(q, h16, s);
         }
         // rgb pyramid: at stage i > 0 the running rgb came from rgb_upsample of the previous sum
         h = hin;
@@ -593,10 +676,18 @@ extern "C" void n3dt_launch_nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderPa
         const int fs = g->featmap_size, HW = fs * fs;
         hipLaunchKernelGGL(nrt_blur_adj_planar_kernel, GRID1((size_t)nb * 3 * 4 * HW), 0, s, nb * 3, 2 * fs, 2 * fs, drgb, dtmp);
         hipLaunchKernelGGL(nrt_bilinear_adj_kernel, GRID1((size_t)nb * 3 * HW), 0, s, nb * 3, fs, fs, dtmp, drgb);
-        launch_to_rgb_wgrad(nb, HW, C, drgb, featmap, gp->to_rgb_w[0], s);
+        launch_to_rgb_wgrad<float>(nb, HW, C, drgb, featmap, gp->to_rgb_w[0], s);
         hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[0]);
-        hipLaunchKernelGGL(nrt_to_rgb_bwd_kernel, GRID1((size_t)nb * HW * (C / 4)), 3 * C * sizeof(float), s, nb, HW, C, drgb,
-                           p->to_rgb_w[0], (const float*)nullptr, dnet, 1);
-        (void)hipMemcpyAsync(d_featmap, dnet, sizeof(float) * (size_t)nb * HW * C, hipMemcpyDeviceToDevice, s);
+        hipLaunchKernelGGL(nrt_to_rgb_bwd_kernel<T>, GRID1((size_t)nb * HW * (C / 4)), 3 * C * sizeof(float), s, nb, HW, C, drgb,
+                           p->to_rgb_w[0], (const T*)nullptr, dnet, 1);
+        const size_t n = (size_t)nb * HW * C;
+        hipLaunchKernelGGL(nrt_to_f32_kernel<T>, GRID1(n), 0, s, n, (const T*)dnet, d_featmap);
     }
+}
+
+extern "C" void n3dt_launch_nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N3dtRenderGrads* gp,
+                                   const float* featmap, const float* d_img, const float* saved, float* d_featmap, float* ws,
+                                   int bf16, hipStream_t s) {
+    if (bf16) nr_bwd<nrt_bf16>(g, nb, p, gp, featmap, d_img, saved, d_featmap, ws, s);
+    else nr_bwd<float>(g, nb, p, gp, featmap, d_img, saved, d_featmap, ws, s);
 }
