@@ -511,6 +511,19 @@ static void set_grad_split(Gemm32& q, long K) {
     q.accumulate = q.split_k <= 1 ? 1 : 0;
 }
 
+extern "C" void n3dt_launch_conv1x1_bf16(int, int, int, const void*, int, const float*, const float*, float, void*, hipStream_t);
+
+// forward 1x1 conv + bias + LeakyReLU(0.2): the exact fp32 GEMM, or (bf16 maps) the renderer's own 16-bit GEMM with its
+// LDS-staged 16-byte stores (neural_render_x16.inc)
+template <class T>
+static void conv_fwd(int M, int N, int K, const void* x, int x16, const float* W, const float* b, T* y, hipStream_t s);
+template <>
+void conv_fwd<float>(int M, int N, int K, const void* x, int, const float* W, const float* b, float* y, hipStream_t s) {
+    Gemm32 q = mk(M, N, K, reinterpret_cast<const float*>(x), K, 0, W, K, 0, y, N);
+    q.bias = b; q.act = G32_ACT_LRELU;
+    n3dt_gemm32(q, s);
+}
+
 // bf16-storage GEMM operands travel through the descriptor's float pointers (gemm32.h)
 template <class T>
 static inline const float* as_f(const T* p) { return reinterpret_cast<const float*>(p); }
@@ -524,6 +537,11 @@ template <class T>
 __global__ void nrt_to_f32_kernel(size_t n, const T* __restrict__ x, float* __restrict__ y) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = nrt_ld(x + i);
+}
+
+template <>
+void conv_fwd<nrt_bf16>(int M, int N, int K, const void* x, int x16, const float* W, const float* b, nrt_bf16* y, hipStream_t s) {
+    n3dt_launch_conv1x1_bf16(M, N, K, x, x16, W, b, 0.2f, y, s);
 }
 
 // featmap [nb][fs*fs][C] -> img [nb,3,P,P]; all intermediates kept in `saved`.
@@ -551,24 +569,16 @@ static void nr_train_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, c
     const T* x = nullptr;  // level 0 reads the fp32 featmap
     for (int i = 0; i < nblk; ++i) {
         const int ci = nr_ch(C, i), co = nr_ch(C, i + 1), M = nb * h * h;
-        Gemm32 q1 = mk(M, 2 * ci, ci, i == 0 ? featmap : as_f(x), ci, 0, p->psu1_w[i], ci, 0, as_f(saved + sv.t1[i]), 2 * ci);
-        q1.bias = p->psu1_b[i]; q1.act = G32_ACT_LRELU;
-        q1.a16 = i == 0 ? 0 : h16; q1.c16 = h16;
-        n3dt_gemm(q1, h16, s);
-        Gemm32 q2 = mk(M, 4 * ci, 2 * ci, as_f(saved + sv.t1[i]), 2 * ci, 0, p->psu2_w[i], 2 * ci, 0, as_f(saved + sv.tv[i]), 4 * ci);
-        q2.bias = p->psu2_b[i]; q2.act = G32_ACT_LRELU;
-        q2.a16 = h16; q2.c16 = h16;
-        n3dt_gemm(q2, h16, s);
+        conv_fwd<T>(M, 2 * ci, ci, i == 0 ? (const void*)featmap : (const void*)x, i == 0 ? 0 : h16, p->psu1_w[i], p->psu1_b[i],
+                    saved + sv.t1[i], s);
+        conv_fwd<T>(M, 4 * ci, 2 * ci, saved + sv.t1[i], h16, p->psu2_w[i], p->psu2_b[i], saved + sv.tv[i], s);
         if (i == 0)
             hipLaunchKernelGGL((nrt_shuffle_kernel<T, float>), GRID1((size_t)M * ci), 0, s, nb, h, h, ci, (const T*)(saved + sv.tv[i]), featmap, ps);
         else
             hipLaunchKernelGGL((nrt_shuffle_kernel<T, T>), GRID1((size_t)M * ci), 0, s, nb, h, h, ci, (const T*)(saved + sv.tv[i]), x, ps);
         h *= 2;
         hipLaunchKernelGGL(nrt_blur_kernel<T>, GRID1((size_t)nb * h * h * (ci / 4)), 0, s, nb, h, h, ci, (const T*)ps, saved + sv.bl[i]);
-        Gemm32 q3 = mk(nb * h * h, co, ci, as_f(saved + sv.bl[i]), ci, 0, p->feat_w[i], ci, 0, as_f(saved + sv.net[i]), co);
-        q3.bias = p->feat_b[i]; q3.act = G32_ACT_LRELU;
-        q3.a16 = h16; q3.c16 = h16;
-        n3dt_gemm(q3, h16, s);
+        conv_fwd<T>(nb * h * h, co, ci, saved + sv.bl[i], h16, p->feat_w[i], p->feat_b[i], saved + sv.net[i], s);
         const bool last = i == nblk - 1;
         hipLaunchKernelGGL(nrt_to_rgb_kernel<T>, GRID1((size_t)nb * h * h), 3 * co * sizeof(float), s, nb, h * h, co,
                            (const T*)(saved + sv.net[i]), p->to_rgb_w[i + 1], p->to_rgb_b[i + 1], (const float*)rgbA, last ? img_saved : rgbB,
