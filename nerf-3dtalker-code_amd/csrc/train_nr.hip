@@ -36,7 +36,7 @@ static NrSaved nr_saved_layout(const N3dtGeom* g, int nb) {
 }
 
 struct NrWs {
-    size_t a, b, c, rgb0, rgb1, total;  // three big ping-pong buffers + two planar rgb gradient buffers
+    size_t a, b, c, rgb0, rgb1, wt, total;  // three big ping-pong buffers, two planar rgb gradient buffers, a transposed weight
 };
 static NrWs nr_ws_layout(const N3dtGeom* g, int nb) {
     NrWs w;
@@ -53,6 +53,7 @@ static NrWs nr_ws_layout(const N3dtGeom* g, int nb) {
     w.c = o; o += al64(big);
     w.rgb0 = o; o += al64((size_t)nb * 3 * P * P);
     w.rgb1 = o; o += al64((size_t)nb * 3 * P * P);
+    w.wt = o; o += al64((size_t)8 * g->feat_nc * g->feat_nc);  // fp32 [2C][4C] at most (layer_2 of stage 0)
     w.total = o;
     return w;
 }
@@ -512,6 +513,22 @@ static void set_grad_split(Gemm32& q, long K) {
 }
 
 extern "C" void n3dt_launch_conv1x1_bf16(int, int, int, const void*, int, const float*, const float*, float, void*, hipStream_t);
+extern "C" void n3dt_launch_conv1x1_bwd_bf16(int, int, int, const void*, const float*, int, const void*, void*, hipStream_t);
+extern "C" void n3dt_launch_chw_to_hwc(int, int, const float*, float*, hipStream_t);
+
+// input gradient of a 1x1 conv: dx[M][Nin] = dy[M][Kout] . W[Kout][Nin], then * lrelu'(gate) (mode 1) or += into dx (mode 2).
+// fp32: the generic GEMM with its k-major B operand; bf16 maps: W is transposed into `wt` ([Nin][Kout], a few hundred KB) and
+// the renderer's 16-bit GEMM runs with a gate / add epilogue.
+template <class T>
+static void conv_bwd_x(int M, int Nin, int Kout, const T* dy, const float* W, int mode, const T* res, T* dx, float* wt, hipStream_t s);
+template <>
+void conv_bwd_x<float>(int M, int Nin, int Kout, const float* dy, const float* W, int mode, const float* res, float* dx, float*,
+                       hipStream_t s) {
+    Gemm32 q = mk(M, Nin, Kout, dy, Kout, 0, W, Nin, 1, dx, Nin);
+    if (mode == 1) { q.gate = res; q.ldgate = Nin; q.gate_act = G32_ACT_LRELU; }
+    if (mode == 2) q.accumulate = 1;
+    n3dt_gemm32(q, s);
+}
 
 // forward 1x1 conv + bias + LeakyReLU(0.2): the exact fp32 GEMM, or (bf16 maps) the renderer's own 16-bit GEMM with its
 // LDS-staged 16-byte stores (neural_render_x16.inc)
@@ -537,6 +554,13 @@ template <class T>
 __global__ void nrt_to_f32_kernel(size_t n, const T* __restrict__ x, float* __restrict__ y) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = nrt_ld(x + i);
+}
+
+template <>
+void conv_bwd_x<nrt_bf16>(int M, int Nin, int Kout, const nrt_bf16* dy, const float* W, int mode, const nrt_bf16* res, nrt_bf16* dx,
+                          float* wt, hipStream_t s) {
+    n3dt_launch_chw_to_hwc(Kout, Nin, W, wt, s);  // W [Kout][Nin] -> [Nin][Kout]
+    n3dt_launch_conv1x1_bwd_bf16(M, Nin, Kout, dy, wt, mode, res, dx, s);
 }
 
 template <>
@@ -639,9 +663,7 @@ static void nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N
             set_grad_split(w, M4);
             n3dt_gemm(w, h16, s);
             launch_nrt_colsum<T>(dnet, (long)co, (long)M4, co, gp->feat_b[i], s);
-            Gemm32 q = mk(M4, ci, co, as_f(dnet), co, 0, p->feat_w[i], ci, 1, as_f(bufB), ci);  // d bl
-            q.a16 = h16; q.c16 = h16;
-            n3dt_gemm(q, h16, s);
+            conv_bwd_x<T>(M4, ci, co, dnet, p->feat_w[i], 0, nullptr, bufB, ws_f + wl.wt, s);  // d bl
         }
         // blur adjoint -> d ps (bufC), then un-shuffle into d tv (bufB, gated) and the residual gradient (bufA)
         hipLaunchKernelGGL(nrt_blur_adj_kernel<T>, GRID1((size_t)M4 * (ci / 4)), 0, s, nb, h, h, ci, (const T*)bufB, bufC);
@@ -655,10 +677,7 @@ static void nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N
             set_grad_split(w, M);
             n3dt_gemm(w, h16, s);
             launch_nrt_colsum<T>(dtv, (long)4 * ci, (long)M, 4 * ci, gp->psu2_b[i], s);
-            Gemm32 q = mk(M, 2 * ci, 4 * ci, as_f(dtv), 4 * ci, 0, p->psu2_w[i], 2 * ci, 1, as_f(bufC), 2 * ci);  // d t1, gated by lrelu'(t1)
-            q.gate = as_f(saved + sv.t1[i]); q.ldgate = 2 * ci; q.gate_act = G32_ACT_LRELU;
-            q.a16 = h16; q.c16 = h16; q.gate16 = h16;
-            n3dt_gemm(q, h16, s);
+            conv_bwd_x<T>(M, 2 * ci, 4 * ci, dtv, p->psu2_w[i], 1, saved + sv.t1[i], bufC, ws_f + wl.wt, s);  // d t1, gated by lrelu'(t1)
         }
         // layer_1: t1 = lrelu(x W1^T + b1);  dx = dt1 W1 + residual gradient
         {
@@ -668,10 +687,7 @@ static void nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N
             set_grad_split(w, M);
             n3dt_gemm(w, h16, s);
             launch_nrt_colsum<T>(bufC, (long)2 * ci, (long)M, 2 * ci, gp->psu1_b[i], s);
-            Gemm32 q = mk(M, ci, 2 * ci, as_f(bufC), 2 * ci, 0, p->psu1_w[i], ci, 1, as_f(dxres), ci);
-            q.accumulate = 1;
-            q.a16 = h16; q.c16 = h16;
-            n3dt_gemm(q, h16, s);
+            conv_bwd_x<T>(M, ci, 2 * ci, bufC, p->psu1_w[i], 2, dxres, dxres, ws_f + wl.wt, s);  // dx = dt1 W1 + residual gradient
         }
         // rgb pyramid: at stage i > 0 the running rgb came from rgb_upsample of the previous sum
         h = hin;
