@@ -549,6 +549,91 @@ static inline float* as_f(T* p) { return reinterpret_cast<float*>(p); }
 template <class T>
 static constexpr int is16() { return sizeof(T) == 2 ? 1 : 0; }
 
+// Weight gradient of a 1x1 conv on bf16 maps: out[co][ci] += sum_pix dY[pix][co] * X[pix][ci].
+// The contraction runs over PIXELS, the row index of both (row-major) operands, with a few dozen to a few hundred output
+// channels: a generic tiled GEMM spends its time transposing 128-wide tiles through LDS for a 32 x 64 result (0.55 TB/s).
+// Here every wave owns TO x TI 32x32 output tiles and a private range of pixels and gathers its MFMA fragments straight from
+// global memory -- lane (r, h) of an A fragment needs dY[pixel 8h+j][channel r], j = 0..7: eight 2-byte loads, each of which is
+// one contiguous 64-byte row segment across the 32 lanes -- so there is no LDS, no barrier, and the operand bytes per MFMA are
+// small enough (1 KiB) that the load pipe is nowhere near its limit.  fp32 atomics combine the pixel ranges.
+typedef __bf16 nrt_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short nrt_u16x8 __attribute__((ext_vector_type(8)));
+template <int TO, int TI, class TX>
+__global__ __launch_bounds__(256) void nrt_dw16_kernel(int co, int ci, long K, const nrt_bf16* __restrict__ dY, const TX* __restrict__ X,
+                                                       float* __restrict__ out, long ldo, long chunk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int tiles_i = (ci / 32 + TI - 1) / TI;
+    const int o0 = (blockIdx.y / tiles_i) * TO * 32, i0 = (blockIdx.y % tiles_i) * TI * 32;
+    // the workgroup's pixel chunk, split evenly over its 4 waves in multiples of 16 pixels
+    const long c0 = (long)blockIdx.x * chunk, c1 = min(K, c0 + chunk);
+    const long per = ((c1 - c0 + 3) / 4 + 15) / 16 * 16;
+    const long p0 = c0 + wave * per, p1 = min(c1, p0 + per);
+    f32x16 acc[TO][TI];
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int b = 0; b < TI; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
+    // channels past the layer's width (a 64 x 128 wave tile on a narrower layer) are clamped to a valid one: their tiles are
+    // computed and dropped.  The main loop takes whole 16-pixel steps with no per-element guards, two steps in flight.
+    auto step = [&](const long p, const bool guard) {
+        nrt_bf16x8 fa[TO], fb[TI];
+        const long pb = p + 8 * h;
+#pragma unroll
+        for (int a = 0; a < TO; ++a) {
+            nrt_u16x8 u;
+            const int ch = min(o0 + 32 * a + r, co - 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = (!guard || pb + j < p1) ? dY[(pb + j) * co + ch].u : (unsigned short)0;
+            fa[a] = __builtin_bit_cast(nrt_bf16x8, u);
+        }
+#pragma unroll
+        for (int b = 0; b < TI; ++b) {
+            nrt_u16x8 u;
+            const int ch = min(i0 + 32 * b + r, ci - 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = (!guard || pb + j < p1) ? nrt_ld(X + (pb + j) * ci + ch) : 0.0f;
+                u[j] = __builtin_bit_cast(unsigned short, (__bf16)v);
+            }
+            fb[b] = __builtin_bit_cast(nrt_bf16x8, u);
+        }
+#pragma unroll
+        for (int a = 0; a < TO; ++a)
+#pragma unroll
+            for (int b = 0; b < TI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    };
+    long p = p0;
+    for (; p + 16 <= p1; p += 16) step(p, false);
+    if (p < p1) step(p, true);
+    if (p0 >= p1) return;
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int b = 0; b < TI; ++b) {
+            const int col = i0 + 32 * b + r;
+            if (col >= ci) continue;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = o0 + 32 * a + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (row < co) atomicAdd(out + (long)row * ldo + col, acc[a][b][q]);
+            }
+        }
+}
+template <class TX>
+static void launch_dw16(int co, int ci, long K, const nrt_bf16* dY, const TX* X, float* out, long ldo, hipStream_t s) {
+    // 64 x 128 outputs per wave (fewer when the layer is smaller); about 512 workgroups of 4 waves, >= 1024 pixels each
+    const int groups = ((co / 32 + 1) / 2) * ((ci / 32 + 3) / 4);
+    long slices = 512 / groups;
+    if (slices > K / 1024) slices = K / 1024;
+    if (slices < 1) slices = 1;
+    const long chunk = ((K + slices - 1) / slices + 63) / 64 * 64;
+    dim3 grid((unsigned)((K + chunk - 1) / chunk), groups);
+    if (co <= 32 && ci <= 64) hipLaunchKernelGGL((nrt_dw16_kernel<1, 2, TX>), dim3(grid.x, 1), dim3(256), 0, s, co, ci, K, dY, X, out, ldo, chunk);
+    else hipLaunchKernelGGL((nrt_dw16_kernel<2, 4, TX>), grid, dim3(256), 0, s, co, ci, K, dY, X, out, ldo, chunk);
+}
+
 // to fp32 at the boundary (d_featmap is fp32 in both modes)
 template <class T>
 __global__ void nrt_to_f32_kernel(size_t n, const T* __restrict__ x, float* __restrict__ y) {
@@ -561,6 +646,24 @@ void conv_bwd_x<nrt_bf16>(int M, int Nin, int Kout, const nrt_bf16* dy, const fl
                           float* wt, hipStream_t s) {
     n3dt_launch_chw_to_hwc(Kout, Nin, W, wt, s);  // W [Kout][Nin] -> [Nin][Kout]
     n3dt_launch_conv1x1_bwd_bf16(M, Nin, Kout, dy, wt, mode, res, dx, s);
+}
+
+// parameter gradient of a 1x1 conv: dW[co][ci] += dy^T x over M pixels
+template <class T, class TX>
+static void conv_bwd_w(int co, int ci, long M, const T* dy, const TX* x, float* dW, hipStream_t s);
+template <>
+void conv_bwd_w<float, float>(int co, int ci, long M, const float* dy, const float* x, float* dW, hipStream_t s) {
+    Gemm32 w = mk(co, ci, (int)M, dy, co, 1, x, ci, 1, dW, ci);
+    set_grad_split(w, M);
+    n3dt_gemm32(w, s);
+}
+template <>
+void conv_bwd_w<nrt_bf16, nrt_bf16>(int co, int ci, long M, const nrt_bf16* dy, const nrt_bf16* x, float* dW, hipStream_t s) {
+    launch_dw16<nrt_bf16>(co, ci, M, dy, x, dW, ci, s);
+}
+template <>
+void conv_bwd_w<nrt_bf16, float>(int co, int ci, long M, const nrt_bf16* dy, const float* x, float* dW, hipStream_t s) {
+    launch_dw16<float>(co, ci, M, dy, x, dW, ci, s);
 }
 
 template <>
@@ -624,7 +727,6 @@ extern "C" void n3dt_launch_nr_train_fwd(const N3dtGeom* g, int nb, const N3dtRe
 template <class T>
 static void nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N3dtRenderGrads* gp, const float* featmap,
                    const float* d_img, const float* saved_f, float* d_featmap, float* ws_f, hipStream_t s) {
-    constexpr int h16 = is16<T>();
     const NrSaved sv = nr_saved_layout(g, nb);
     const NrWs wl = nr_ws_layout(g, nb);
     const int C = g->feat_nc, nblk = g->n_blocks;
@@ -658,10 +760,7 @@ static void nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N
         }
         // feat conv: net = lrelu(bl Wf^T + bf)
         {
-            Gemm32 w = mk(co, ci, M4, as_f(dnet), co, 1, as_f(saved + sv.bl[i]), ci, 1, gp->feat_w[i], ci);
-            w.a16 = h16; w.b16 = h16;
-            set_grad_split(w, M4);
-            n3dt_gemm(w, h16, s);
+            conv_bwd_w<T, T>(co, ci, M4, (const T*)dnet, saved + sv.bl[i], gp->feat_w[i], s);
             launch_nrt_colsum<T>(dnet, (long)co, (long)M4, co, gp->feat_b[i], s);
             conv_bwd_x<T>(M4, ci, co, dnet, p->feat_w[i], 0, nullptr, bufB, ws_f + wl.wt, s);  // d bl
         }
@@ -672,20 +771,14 @@ static void nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N
         T* dxres = bufA;  // [M][ci]
         // layer_2: tv = lrelu(t1 W2^T + b2)
         {
-            Gemm32 w = mk(4 * ci, 2 * ci, M, as_f(dtv), 4 * ci, 1, as_f(saved + sv.t1[i]), 2 * ci, 1, gp->psu2_w[i], 2 * ci);
-            w.a16 = h16; w.b16 = h16;
-            set_grad_split(w, M);
-            n3dt_gemm(w, h16, s);
+            conv_bwd_w<T, T>(4 * ci, 2 * ci, M, (const T*)dtv, saved + sv.t1[i], gp->psu2_w[i], s);
             launch_nrt_colsum<T>(dtv, (long)4 * ci, (long)M, 4 * ci, gp->psu2_b[i], s);
             conv_bwd_x<T>(M, 2 * ci, 4 * ci, dtv, p->psu2_w[i], 1, saved + sv.t1[i], bufC, ws_f + wl.wt, s);  // d t1, gated by lrelu'(t1)
         }
         // layer_1: t1 = lrelu(x W1^T + b1);  dx = dt1 W1 + residual gradient
         {
-            Gemm32 w = i == 0 ? mk(2 * ci, ci, M, as_f(bufC), 2 * ci, 1, featmap, ci, 1, gp->psu1_w[i], ci)
-                              : mk(2 * ci, ci, M, as_f(bufC), 2 * ci, 1, as_f(saved + sv.net[i - 1]), ci, 1, gp->psu1_w[i], ci);
-            w.a16 = h16; w.b16 = i == 0 ? 0 : h16;
-            set_grad_split(w, M);
-            n3dt_gemm(w, h16, s);
+            if (i == 0) conv_bwd_w<T, float>(2 * ci, ci, M, (const T*)bufC, featmap, gp->psu1_w[i], s);
+            else conv_bwd_w<T, T>(2 * ci, ci, M, (const T*)bufC, saved + sv.net[i - 1], gp->psu1_w[i], s);
             launch_nrt_colsum<T>(bufC, (long)2 * ci, (long)M, 2 * ci, gp->psu1_b[i], s);
             conv_bwd_x<T>(M, ci, 2 * ci, bufC, p->psu1_w[i], 2, dxres, dxres, ws_f + wl.wt, s);  // dx = dt1 W1 + residual gradient
         }
