@@ -1,6 +1,8 @@
 // Training path of the 2-D neural renderer: forward that keeps every stage's activations, and the
 // backward (adjoints of the 1x1 convs, pixel-shuffle + residual, reflect-border blur, bilinear x2 and
-// the RGB skip pyramid).  Exact fp32; every conv product is a gemm32 launch.
+// the RGB skip pyramid).  Written once, templated on the storage element of the maps:
+//   float     exact fp32, every conv product a gemm32 launch (the path pinned against the reference's autograd);
+//   nrt_bf16  mixed precision: bf16 maps and map gradients in HBM, bf16 MFMA products, fp32 parameters and gradients.
 //
 // Differentiates (reference): NetWorks/neural_renderer.py:72-91, NetWorks/PixelShuffleUpsample.py:36-45,
 // Blur :15-18 (kornia filter2d semantics).
