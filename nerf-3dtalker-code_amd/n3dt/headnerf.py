@@ -259,7 +259,7 @@ class HeadNeRFNet(nn.Module):
         super().__init__()
         # hier_sampling=True: the reference builds FineSample + a second MLP (HeadNeRFNet.py:67-74) but its call site omits
         # two arguments (:182-185) and raises TypeError; here the fine pass runs, with those arguments supplied
-        # (inference; the differentiable path covers the coarse network only)
+        # (inference and training; camera gradients through the fine pass are the one thing not built)
         if include_vd:
             raise NotImplementedError("include_vd=True is never used by the reference's callers and not built here")
         self.hier_sampling = hier_sampling
@@ -380,9 +380,8 @@ class HeadNeRFNet(nn.Module):
             any(p.requires_grad for p in self.parameters()) or
             any(torch.is_tensor(t) and t.requires_grad for t in (audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs)))
         if needs_grad:
-            if self.hier_sampling:
-                raise NotImplementedError("the differentiable path covers the coarse network; run hier_sampling=True under torch.no_grad()")
-            return self._forward_train(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand)
+            return self._forward_train(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand,
+                                       for_train=for_train, fine_u=fine_u)
         # the merged maps (coarse, then fine) and the background map go through the 2-D renderer in one call; the
         # render kernel writes its merged maps straight into that batch
         n_pass = 2 if self.hier_sampling else 1
@@ -405,9 +404,11 @@ class HeadNeRFNet(nn.Module):
             res["fine_dict"] = {"merge_img": imgs[batch_size:nb], "bg_img": imgs[nb:]}
         return res
 
-    def _forward_train(self, batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand):
-        """Differentiable forward (exact fp32): gradients reach every parameter, audiostyle, shape_code, appea_code and
-        (when they require grad) batch_Rmats / batch_Tvecs."""
+    def _forward_train(self, batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand,
+                       for_train=False, fine_u=None):
+        """Differentiable forward: gradients reach every parameter, audiostyle, shape_code, appea_code and (when they require
+        grad) batch_Rmats / batch_Tvecs.  With hier_sampling the fine pass is differentiated too; its sample planes come
+        from the DETACHED coarse weights, as in the reference (NetWorks/utils.py:219), so they are constants of the backward."""
         B, _, n_r = batch_xy.size()
         fs, C = self.featmap_size, self.featmap_nc
         xy = batch_xy if batch_xy.dtype == torch.float32 else batch_xy.float()
@@ -417,10 +418,29 @@ class HeadNeRFNet(nn.Module):
         audio = audiostyle if self.audio_dim > 0 else torch.zeros(B, 0, device=xy.device)
         merge = _RenderFn.apply(self, geom, xy.detach(), ops._f32c(batch_inv_inmats), None if t_rand is None else ops._f32c(t_rand),
                                 batch_Rmats, batch_Tvecs, shape_code, appea_code, audio, self.neural_render.bg_featmap, *mlp)
+        passes = [merge.view(B, fs, fs, C)]
+        if self.hier_sampling:
+            if any(torch.is_tensor(t) and t.requires_grad for t in (batch_Rmats, batch_Tvecs)):
+                raise NotImplementedError("camera gradients through the hierarchical pass are not built")
+            with torch.no_grad():
+                w = self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
+                                         t_rand=t_rand, want_weight=True, want_merge=False, precision=self.train_precision)["weight"]
+                if for_train and fine_u is None:  # the reference's torch.rand(num_temp, NFsample) (NetWorks/utils.py:227)
+                    fine_u = torch.rand(B * n_r, self.num_sample_fine + 1, device=xy.device, dtype=torch.float32)
+                planes = self.fine_planes(batch_xy, w, batch_Tvecs, t_rand=t_rand, fine_u=fine_u)
+            gfine = self._geom(B, n_r, xy, n_samples=planes.shape[-1] - 1, z_planes_given=1)
+            flayers = self.fine_fg_CD_predictor.layers()
+            fmlp = [m.weight for m in flayers] + [m.bias for m in flayers]
+            fmerge = _RenderFn.apply(self, gfine, xy.detach(), ops._f32c(batch_inv_inmats), planes, batch_Rmats, batch_Tvecs, shape_code,
+                                     appea_code, audio, self.neural_render.bg_featmap, *fmlp)
+            passes.append(fmerge.view(B, fs, fs, C))
         bg_hwc = self.neural_render.bg_featmap.view(C, fs * fs).t().reshape(1, fs, fs, C)
-        maps = torch.cat([merge.view(B, fs, fs, C), bg_hwc], dim=0)
-        imgs = self.neural_render.render_hwc_train(maps)
-        return {"coarse_dict": {"merge_img": imgs[:B], "bg_img": imgs[B:]}}
+        nb = B * len(passes)
+        imgs = self.neural_render.render_hwc_train(torch.cat(passes + [bg_hwc], dim=0))
+        res = {"coarse_dict": {"merge_img": imgs[:B], "bg_img": imgs[nb:]}}
+        if self.hier_sampling:
+            res["fine_dict"] = {"merge_img": imgs[B:nb], "bg_img": imgs[nb:]}
+        return res
 
     def forward(self, mode, batch_xy, batch_uv, audiostyle=None, bg_code=None, shape_code=None, appea_code=None,
                 batch_Rmats=None, batch_Tvecs=None, batch_inv_inmats=None, dist_expr=False, **kwargs):

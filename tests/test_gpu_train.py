@@ -294,3 +294,52 @@ def test_renderer_gradients_at_a_non_power_of_two_map_are_directional_derivative
                 p.sub_(sgn * h * u)
     numeric = (vals[0] - vals[1]) / (2 * h)
     assert abs(numeric - analytic) <= 2e-2 * abs(analytic) + 1e-6, (numeric, analytic)
+
+
+def test_hierarchical_pass_is_differentiable():
+    """hier_sampling=True under autograd: the training forward reproduces the inference images of both passes, and the
+    gradient of a loss on the FINE image with respect to the fine network matches a central finite difference along a random
+    direction (the planes come from the detached coarse weights, NetWorks/utils.py:219, so they do not move)."""
+    from n3dt import HeadNeRFNet, BaseOptions, synthetic as syn
+    opt = BaseOptions({"featmap_size": 8, "featmap_nc": 256, "pred_img_size": 32, "num_sample_coarse": 16, "num_sample_fine": 24})
+    sd = syn.make_state_dict(opt, seed=2, bg_noise=0.1, hier_sampling=True)
+    net = HeadNeRFNet(opt, False, True).to(dev())
+    net.load_state_dict(sd)
+    B = 2
+    d = {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in syn.frame_inputs(opt, B).items()}
+
+    def run():
+        return net("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+                   d["batch_Tvecs"], d["batch_inv_inmats"])
+
+    with torch.no_grad():
+        ref = run()
+    out = run()
+    for k in ("coarse_dict", "fine_dict"):
+        assert float((out[k]["merge_img"] - ref[k]["merge_img"]).abs().max()) <= 1e-5, k
+    params = [p for n, p in net.named_parameters() if n.startswith("fine_fg_CD_predictor")]
+    loss = ((out["fine_dict"]["merge_img"] - 0.4) ** 2).mean()
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+    assert net.fg_CD_predictor.FeaExt_module_3.weight.grad.abs().sum() == 0  # the fine image does not depend on the coarse network
+    gen = torch.Generator().manual_seed(4)
+    dirs = [torch.randn(p.shape, generator=gen).to(dev()) * p.detach().abs().mean() for p in params]
+    analytic = sum(float((p.grad * u).sum()) for p, u in zip(params, dirs))
+    h, vals = 2e-3, []
+    with torch.no_grad():
+        for sgn in (+1.0, -1.0):
+            for p, u in zip(params, dirs):
+                p.add_(sgn * h * u)
+            vals.append(float(((run()["fine_dict"]["merge_img"] - 0.4) ** 2).mean().double()))
+            for p, u in zip(params, dirs):
+                p.sub_(sgn * h * u)
+    numeric = (vals[0] - vals[1]) / (2 * h)
+    assert abs(numeric - analytic) <= 5e-2 * abs(analytic) + 1e-7, (numeric, analytic)
+    # mixed precision runs the same graph
+    net.train_precision = "bf16"
+    net.neural_render.train_precision = "bf16"
+    net.zero_grad()
+    o16 = run()
+    ((o16["fine_dict"]["merge_img"] - 0.4) ** 2).mean().backward()
+    assert float((o16["fine_dict"]["merge_img"] - ref["fine_dict"]["merge_img"]).abs().max()) <= 5e-3
+    assert all(torch.isfinite(p.grad).all() for p in params)
