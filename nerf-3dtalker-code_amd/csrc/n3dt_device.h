@@ -133,6 +133,37 @@ __device__ __forceinline__ N3dtDiv n3dt_div(const unsigned d) {
 __device__ __forceinline__ size_t n3dt_quot(const size_t x, const N3dtDiv v) { return v.sh >= 0 ? x >> v.sh : x / v.d; }
 __device__ __forceinline__ int n3dt_rem(const size_t x, const N3dtDiv v) { return v.sh >= 0 ? (int)(x & (v.d - 1)) : (int)(x % v.d); }
 
+// rgb_upsample = bilinear x2 (align_corners=False) followed by the reflect-border [1,2,1]/4 blur (neural_renderer.py:54-55),
+// along one axis, in closed form: output o of the 2n-long axis is a combination of the inputs base-1, base, base+1
+// (base = o >> 1).  The blur reads the upsampled values at reflect(o-1), o, reflect(o+1); an even upsampled index 2m is
+// 0.25 x[m-1] + 0.75 x[m], an odd one 2m+1 is 0.75 x[m] + 0.25 x[m+1], indices clamped to the axis -- all inside the window.
+// Slots whose input index falls off the axis keep weight 0.  (Evaluating the nine bilinear samples separately costs 36 loads
+// per output pixel; this is 9.)
+__device__ __forceinline__ void n3dt_up_blur_w3(const int o, const int n, float (&w3)[3]) {
+    const int base = o >> 1;
+    w3[0] = w3[1] = w3[2] = 0.0f;
+#pragma unroll
+    for (int d = -1; d <= 1; ++d) {
+        int i = o + d;
+        i = i < 0 ? -i : (i >= 2 * n ? 4 * n - 2 - i : i);  // reflect on the 2n-long axis
+        const float kd = d == 0 ? 0.5f : 0.25f;
+        const int m = i >> 1;
+        int a0, a1;
+        float f0, f1;
+        if ((i & 1) == 0) {
+            a0 = max(m - 1, 0); f0 = 0.25f;
+            a1 = m; f1 = 0.75f;
+        } else {
+            a0 = m; f0 = 0.75f;
+            a1 = min(m + 1, n - 1); f1 = 0.25f;
+        }
+        const int s0 = a0 - base + 1, s1 = a1 - base + 1;
+        w3[0] += (s0 == 0 ? kd * f0 : 0.0f) + (s1 == 0 ? kd * f1 : 0.0f);
+        w3[1] += (s0 == 1 ? kd * f0 : 0.0f) + (s1 == 1 ? kd * f1 : 0.0f);
+        w3[2] += (s0 == 2 ? kd * f0 : 0.0f) + (s1 == 2 ? kd * f1 : 0.0f);
+    }
+}
+
 // exclusive prefix product over `width` consecutive lanes (width 16 or 32, power of two)
 template <int WIDTH>
 __device__ __forceinline__ float n3dt_exclusive_prod(float x, int lane_in_group) {

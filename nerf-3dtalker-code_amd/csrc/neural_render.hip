@@ -160,13 +160,17 @@ __global__ void rgb_up_kernel(int n_planes, int h, int w, const float* __restric
     int oj = n3dt_rem(i, dW2), oi = n3dt_rem(orow, dH2);
     size_t pl = n3dt_quot(orow, dH2);
     const float* xp = x + pl * (size_t)h * w;
-    const float k[3] = {0.25f, 0.5f, 0.25f};
+    float wr[3], wc[3];
+    n3dt_up_blur_w3(oi, h, wr);
+    n3dt_up_blur_w3(oj, w, wc);
+    const int bi = oi >> 1, bj = oj >> 1;
     float acc = 0.0f;
 #pragma unroll
-    for (int di = -1; di <= 1; ++di)
+    for (int a = 0; a < 3; ++a) {
+        const int ii = min(max(bi - 1 + a, 0), h - 1);
 #pragma unroll
-        for (int dj = -1; dj <= 1; ++dj)
-            acc += (k[di + 1] * k[dj + 1]) * bilinear_at(xp, h, w, reflect1(oi + di, H2), reflect1(oj + dj, W2));
+        for (int b = 0; b < 3; ++b) acc += (wr[a] * wc[b]) * xp[(size_t)ii * w + min(max(bj - 1 + b, 0), w - 1)];
+    }
     y[i] = acc;
 }
 
