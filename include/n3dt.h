@@ -152,6 +152,27 @@ int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, co
 int n3dt_fine_sample(const N3dtGeom* g, int n_fine, const float* weight, const float* T, const float* t_rand, const float* u,
                      float* z_planes, void* stream);
 
+/* ---- the reference's inner seams as stand-alone operators ------------------------------------------
+ * HeadNeRFNet keeps its sub-modules addressable (sample_func, vp_encoder, fg_CD_predictor, calc_color_func).
+ * n3dt_render_fwd never materialises the tensors that cross those seams; these four calls do, in the reference's own
+ * layouts, for callers that use the sub-modules directly.  Exact fp32, unfused, inference only.  M = N_r * N_s.
+ *   n3dt_sample_points  GenSamplePoints.forward (NetWorks/utils.py:147-161): pts [B,3,N_r,N_s], zvals / z_dists
+ *                       [B,1,N_r,N_s], ray_d [B,3,N_r], ray_l [B,1,N_r] (outputs may be NULL); t_rand as in n3dt_render_fwd
+ *   n3dt_embed          Embedder.forward (utils.py:43-51): pts [B,3,M] -> pe [B,63,M]
+ *   n3dt_mlp_points     MLPforNeRF.forward (NetWorks/models.py:62-87): audio [B,audio_dim,M] (NULL iff audio_dim == 0),
+ *                       embed_vps [B,63+shape_dim,M], embed_vds [B,appea_dim,M] -> rgb [B,256,M], density [B,1,M]
+ *                       (g supplies batch and the code widths; workspace from n3dt_mlp_points_workspace_bytes)
+ *   n3dt_composite      CalcRayColor.forward (utils.py:291-309): rgb [B,C,N_r,N_s], density / z_dists / zvals
+ *                       [B,1,N_r,N_s] -> feat [B,C,N_r], bg_alpha / depth [B,1,N_r], weight [B,1,N_r,N_s] (last three nullable) */
+int n3dt_sample_points(const N3dtGeom* g, const float* xy, const float* R, const float* T, const float* Kinv, const float* t_rand,
+                       float* pts, float* zvals, float* z_dists, float* ray_d, float* ray_l, void* stream);
+int n3dt_embed(int batch, size_t m, const float* pts, float* pe, void* stream);
+size_t n3dt_mlp_points_workspace_bytes(const N3dtGeom* g, size_t m);
+int n3dt_mlp_points(const N3dtGeom* g, size_t m, const N3dtMlpParams* p, const float* audio, const float* embed_vps,
+                    const float* embed_vds, float* rgb, float* density, void* workspace, size_t workspace_bytes, void* stream);
+int n3dt_composite(int batch, int n_rays, int n_samples, int channels, const float* rgb, const float* density, const float* z_dists,
+                   const float* zvals, float* feat, float* bg_alpha, float* depth, float* weight, void* stream);
+
 /* ---- 2-D neural renderer: a8..a10 ----------------------------------------------------------------
  * Replaces NeuralRenderer.forward (NetWorks/neural_renderer.py:72-91) including
  * PixelShuffleUpsample.forward (PixelShuffleUpsample.py:36-45) and Blur (…:15-18, kornia filter2d).

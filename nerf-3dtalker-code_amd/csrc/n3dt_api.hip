@@ -17,6 +17,14 @@ void n3dt_launch_ray_head(const N3dtGeom*, int, int, const float*, const float*,
 void n3dt_launch_ray_head_mfma(const N3dtGeom*, int, int, const float*, const float*, const float*, const float*, int, float*, float*,
                                float*, float*, float*, float*, hipStream_t);
 void n3dt_launch_chw_to_hwc(int, int, const float*, float*, hipStream_t);
+void n3dt_launch_sample_points(const N3dtGeom*, const float*, const float*, const float*, const float*, const float*, float*, float*,
+                               float*, float*, float*, hipStream_t);
+void n3dt_launch_embed(int, size_t, const float*, float*, hipStream_t);
+size_t n3dt_seam_mlp_ws_floats(const N3dtGeom*, size_t);
+void n3dt_launch_mlp_points(const N3dtGeom*, size_t, const N3dtMlpParams*, const float*, const float*, const float*, float*, float*, float*,
+                            hipStream_t);
+void n3dt_launch_composite(int, int, int, int, const float*, const float*, const float*, const float*, float*, float*, float*, float*,
+                           hipStream_t);
 void n3dt_launch_fine_sample(const N3dtGeom*, int, const float*, const float*, const float*, const float*, float*, hipStream_t);
 void n3dt_launch_nerf_fwd_f32(const N3dtGeom*, const N3dtMlpParams*, const void*, const float*, const float*, const float*,
                               const float*, const float*, const float*, float*, float*, hipStream_t);
@@ -209,6 +217,53 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
     else
         n3dt_launch_ray_head_mfma(g, c.bpr, c.bs, part, wlocal, tail, bghwc, 1, fg_feat, bg_alpha, depth, weight, merge_feat, nullptr, s);
     return check_hip("n3dt_render_fwd");
+}
+
+// ---- stand-alone seams (csrc/seams.hip) ------------------------------------------------------------
+extern "C" int n3dt_sample_points(const N3dtGeom* g, const float* xy, const float* R, const float* T, const float* Kinv,
+                                  const float* t_rand, float* pts, float* zvals, float* z_dists, float* ray_d, float* ray_l, void* stream) {
+    int rc = check_geom(g, N3DT_F32);
+    if (rc) return rc;
+    if (!xy || !R || !T || !Kinv) return fail(N3DT_EINVAL, "n3dt_sample_points: NULL argument");
+    if (g->z_planes_given && !t_rand) return fail(N3DT_EINVAL, "n3dt_sample_points: z_planes_given but no planes passed as t_rand");
+    n3dt_launch_sample_points(g, xy, R, T, Kinv, t_rand, pts, zvals, z_dists, ray_d, ray_l, (hipStream_t)stream);
+    return check_hip("n3dt_sample_points");
+}
+
+extern "C" int n3dt_embed(int batch, size_t m, const float* pts, float* pe, void* stream) {
+    if (batch < 1 || m < 1 || !pts || !pe) return fail(N3DT_EINVAL, "n3dt_embed: bad argument");
+    n3dt_launch_embed(batch, m, pts, pe, (hipStream_t)stream);
+    return check_hip("n3dt_embed");
+}
+
+extern "C" size_t n3dt_mlp_points_workspace_bytes(const N3dtGeom* g, size_t m) {
+    if (check_geom(g, N3DT_F32) != N3DT_OK || m < 1) return 0;
+    return n3dt_seam_mlp_ws_floats(g, m) * sizeof(float);
+}
+
+extern "C" int n3dt_mlp_points(const N3dtGeom* g, size_t m, const N3dtMlpParams* p, const float* audio, const float* embed_vps,
+                               const float* embed_vds, float* rgb, float* density, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_geom(g, N3DT_F32);
+    if (rc) return rc;
+    if (m < 1 || !p || !embed_vps || !embed_vds || !rgb || !density || !workspace) return fail(N3DT_EINVAL, "n3dt_mlp_points: NULL argument");
+    if (g->audio_dim > 0 && !audio) return fail(N3DT_EINVAL, "n3dt_mlp_points: audio is NULL but audio_dim > 0");
+    if ((size_t)g->batch * m > (size_t)1 << 30) return fail(N3DT_EINVAL, "n3dt_mlp_points: more than 2^30 points");
+    if (workspace_bytes < n3dt_mlp_points_workspace_bytes(g, m)) return fail(N3DT_EWORKSPACE, "n3dt_mlp_points: workspace too small");
+    for (int l = 0; l < N3DT_MLP_LAYERS; ++l)
+        if (!p->weight[l] || !p->bias[l]) return fail(N3DT_EINVAL, "n3dt_mlp_points: NULL parameter pointer");
+    n3dt_launch_mlp_points(g, m, p, audio, embed_vps, embed_vds, rgb, density, (float*)workspace, (hipStream_t)stream);
+    return check_hip("n3dt_mlp_points");
+}
+
+extern "C" int n3dt_composite(int batch, int n_rays, int n_samples, int channels, const float* rgb, const float* density,
+                              const float* z_dists, const float* zvals, float* feat, float* bg_alpha, float* depth, float* weight,
+                              void* stream) {
+    if (batch < 1 || n_rays < 1 || n_samples < 1 || channels < 1 || !rgb || !density || !z_dists || !zvals || !feat)
+        return fail(N3DT_EINVAL, "n3dt_composite: bad argument");
+    if (n_samples > 4096) return fail(N3DT_EINVAL, "n3dt_composite: more than 4096 samples per ray");
+    n3dt_launch_composite(batch, n_rays, n_samples, channels, rgb, density, z_dists, zvals, feat, bg_alpha, depth, weight,
+                          (hipStream_t)stream);
+    return check_hip("n3dt_composite");
 }
 
 extern "C" int n3dt_fine_sample(const N3dtGeom* g, int n_fine, const float* weight, const float* T, const float* t_rand, const float* u,

@@ -49,6 +49,7 @@ EXPORTS = [
     "n3dt_render_train_saved_bytes", "n3dt_render_train_workspace_bytes", "n3dt_render_train_fwd", "n3dt_render_bwd",
     "n3dt_neural_render_train_saved_bytes", "n3dt_neural_render_train_workspace_bytes",
     "n3dt_neural_render_train_fwd", "n3dt_neural_render_bwd", "n3dt_loss_fwd", "n3dt_loss_bwd", "n3dt_fine_sample",
+    "n3dt_sample_points", "n3dt_embed", "n3dt_mlp_points_workspace_bytes", "n3dt_mlp_points", "n3dt_composite",
 ]
 
 _LIB = None
@@ -110,6 +111,16 @@ def lib():
     L.n3dt_prof_collect.argtypes = [ctypes.POINTER(ctypes.c_float), ci, ctypes.POINTER(ci)]
     L.n3dt_fine_sample.restype = ci
     L.n3dt_fine_sample.argtypes = [gp, ci, vp, vp, vp, vp, vp, vp]
+    L.n3dt_sample_points.restype = ci
+    L.n3dt_sample_points.argtypes = [gp] + [vp] * 10 + [vp]
+    L.n3dt_embed.restype = ci
+    L.n3dt_embed.argtypes = [ci, sz, vp, vp, vp]
+    L.n3dt_mlp_points_workspace_bytes.restype = sz
+    L.n3dt_mlp_points_workspace_bytes.argtypes = [gp, sz]
+    L.n3dt_mlp_points.restype = ci
+    L.n3dt_mlp_points.argtypes = [gp, sz, mp] + [vp] * 5 + [vp, sz, vp]
+    L.n3dt_composite.restype = ci
+    L.n3dt_composite.argtypes = [ci, ci, ci, ci] + [vp] * 8 + [vp]
     if L.n3dt_abi_version() != 2:
         raise N3dtError("libn3dt.so ABI version mismatch")
     _LIB = L

@@ -66,10 +66,17 @@ class MLPforNeRF(nn.Module):
     def layers(self):
         return [self._modules[n] for n in _lib.MLP_ORDER]
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError(
-            "the per-sample [B,C,N_r,N_s] MLP output is never materialised by the fused kernel; "
-            "call HeadNeRFNet.render_features() for the composited result")
+    @torch.no_grad()
+    def forward(self, audiostyle, batch_embed_vps, batch_embed_vds):
+        """The reference's stand-alone seam (NetWorks/models.py:62-87): inputs [B,C,N_r,N_s] -> (rgb, density).
+        Unfused, exact fp32, inference only -- HeadNeRFNet.forward() never materialises these tensors."""
+        B = batch_embed_vps.shape[0]
+        ws = [m.w2d().detach() for m in self.layers()]
+        bs = [m.bias.detach() for m in self.layers()]
+        geom = ops.make_geom(B, 1, 1, self.h_channel, self.res_nfeat, self.vp_channels - 63, self.vd_channels, self.audio_dim, 2, 1,
+                             0.0, 0.0)
+        return ops.mlp_points(geom, ops.mlp_params(ws, bs), audiostyle if self.audio_dim > 0 else None, batch_embed_vps,
+                              batch_embed_vds)
 
 
 class Blur(nn.Module):
@@ -243,14 +250,56 @@ class _NeuralRenderFn(torch.autograd.Function):
 
 
 class _Seam(nn.Module):
-    """Parameter-less seam kept for attribute compatibility (sample_func / vp_encoder / calc_color_func)."""
+    """Parameter-less seam kept for attribute compatibility where no stand-alone operator exists (FineSample)."""
 
     def __init__(self, what):
         super().__init__()
         self.what = what
 
     def forward(self, *a, **k):
-        raise NotImplementedError("%s is fused into n3dt_render_fwd; use HeadNeRFNet.render_features()" % self.what)
+        raise NotImplementedError("%s is fused into the render calls; use HeadNeRFNet.fine_planes()" % self.what)
+
+
+class GenSamplePoints(nn.Module):
+    """sample_func seam (NetWorks/utils.py:55-161) as a stand-alone operator: same call, same result dict."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.world_z1, self.world_z2, self.n_sample_fg = opt.world_z1, opt.world_z2, opt.num_sample_coarse
+
+    @torch.no_grad()
+    def forward(self, batch_xy, batch_Rmat, batch_Tvec, batch_inv_inmat, disturb, t_rand=None):
+        B, _, n_r = batch_xy.shape
+        xy = batch_xy if batch_xy.dtype == torch.float32 else batch_xy.float()
+        if disturb and t_rand is None:  # the reference's torch.rand_like(zvals) (utils.py:77)
+            t_rand = torch.rand(B, n_r, self.n_sample_fg + 1, device=xy.device, dtype=torch.float32)
+        geom = ops.make_geom(B, n_r, self.n_sample_fg, 384, 256, 179, 127, 64, 2, 1, self.world_z1, self.world_z2, xy.stride())
+        T = ops._f32c(batch_Tvec).view(B, 3)
+        o = ops.sample_points(geom, xy, ops._f32c(batch_Rmat), T, ops._f32c(batch_inv_inmat), None if t_rand is None else ops._f32c(t_rand))
+        ray_d = o["ray_d"].unsqueeze(-1)
+        return {"pts": o["pts"], "dirs": ray_d.expand(-1, -1, -1, self.n_sample_fg), "zvals": o["zvals"], "z_dists": o["z_dists"],
+                "batch_ray_o": T.view(B, 3, 1, 1).expand(B, 3, n_r, 1), "batch_ray_d": ray_d, "batch_ray_l": o["ray_l"].unsqueeze(-1)}
+
+
+class Embedder(nn.Module):
+    """vp_encoder seam (NetWorks/utils.py:6-51): [B,3,...] -> [B,63,...]."""
+
+    def __init__(self, N_freqs=10, include_input=True):
+        super().__init__()
+        assert N_freqs == 10 and include_input, "the kernels are built for the reference's 10 frequencies + input"
+        self.N_freqs, self.include_input = N_freqs, include_input
+
+    @torch.no_grad()
+    def forward(self, x):
+        return ops.embed(x)
+
+
+class CalcRayColor(nn.Module):
+    """calc_color_func seam (NetWorks/utils.py:268-309): same call, same 4-tuple."""
+
+    @torch.no_grad()
+    def forward(self, fg_vps, batch_rgb, batch_density, batch_dists, batch_z_vals):
+        return ops.composite(batch_rgb, batch_density, batch_dists, batch_z_vals)
 
 
 class HeadNeRFNet(nn.Module):
@@ -293,15 +342,15 @@ class HeadNeRFNet(nn.Module):
         if self.include_gaze:
             vp_channels += self.eye_gaze_dim
         vd_channels = self.base_appea_code_dims
-        self.vp_encoder = _Seam("Embedder")
-        self.sample_func = _Seam("GenSamplePoints")
+        self.vp_encoder = Embedder(N_freqs=self.vp_n_freqs, include_input=self.include_input_for_vp_embeder)
+        self.sample_func = GenSamplePoints(self.opt)
         self.fg_CD_predictor = MLPforNeRF(vp_channels=vp_channels, vd_channels=vd_channels, h_channel=self.mlp_h_channel,
                                           res_nfeat=self.featmap_nc, audio_dim=self.audio_dim)
         if self.hier_sampling:
             self.fine_samp_func = _Seam("FineSample")
             self.fine_fg_CD_predictor = MLPforNeRF(vp_channels=vp_channels, vd_channels=vd_channels, h_channel=self.mlp_h_channel,
                                                    res_nfeat=self.featmap_nc, audio_dim=self.audio_dim)
-        self.calc_color_func = _Seam("CalcRayColor")
+        self.calc_color_func = CalcRayColor()
         self.neural_render = NeuralRenderer(bg_type=self.opt.bg_type, feat_nc=self.featmap_nc, out_dim=3, final_actvn=True,
                                             min_feat=32, featmap_size=self.featmap_size, img_size=self.pred_img_size)
 

@@ -129,6 +129,61 @@ def fine_sample(geom, n_fine, weight, T, t_rand=None, u=None):
     return z
 
 
+# ---- the reference's inner seams as stand-alone operators (csrc/seams.hip) -------------------------------------
+def sample_points(geom, xy, R, T, Kinv, t_rand=None):
+    """GenSamplePoints.forward: dict of pts [B,3,Nr,Ns], zvals / z_dists [B,1,Nr,Ns], ray_d [B,3,Nr], ray_l [B,1,Nr]."""
+    B, Nr, Ns, dev = geom.batch, geom.n_rays, geom.n_samples, xy.device
+    out = {"pts": torch.empty(B, 3, Nr, Ns, dtype=torch.float32, device=dev),
+           "zvals": torch.empty(B, 1, Nr, Ns, dtype=torch.float32, device=dev),
+           "z_dists": torch.empty(B, 1, Nr, Ns, dtype=torch.float32, device=dev),
+           "ray_d": torch.empty(B, 3, Nr, dtype=torch.float32, device=dev),
+           "ray_l": torch.empty(B, 1, Nr, dtype=torch.float32, device=dev)}
+    check(lib().n3dt_sample_points(ctypes.byref(geom), _ptr(xy), _ptr(R), _ptr(T), _ptr(Kinv), _ptr(t_rand), _ptr(out["pts"]),
+                                   _ptr(out["zvals"]), _ptr(out["z_dists"]), _ptr(out["ray_d"]), _ptr(out["ray_l"]), _stream()),
+          "n3dt_sample_points")
+    return out
+
+
+def embed(pts):
+    """Embedder.forward: pts [B,3,...] -> [B,63,...]."""
+    pts = _f32c(pts)
+    B = pts.shape[0]
+    M = pts[0, 0].numel()
+    pe = torch.empty((B, 63) + tuple(pts.shape[2:]), dtype=torch.float32, device=pts.device)
+    check(lib().n3dt_embed(B, M, _ptr(pts), _ptr(pe), _stream()), "n3dt_embed")
+    return pe
+
+
+def mlp_points(geom, params, audio, embed_vps, embed_vds):
+    """MLPforNeRF.forward on materialised inputs [B,C,Nr,Ns]: returns (rgb [B,256,Nr,Ns], density [B,1,Nr,Ns])."""
+    vps, vds = _f32c(embed_vps), _f32c(embed_vds)
+    aud = _f32c(audio) if geom.audio_dim > 0 else None
+    B = vps.shape[0]
+    M = vps[0, 0].numel()
+    tail = tuple(vps.shape[2:])
+    rgb = torch.empty((B, geom.feat_nc) + tail, dtype=torch.float32, device=vps.device)
+    dens = torch.empty((B, 1) + tail, dtype=torch.float32, device=vps.device)
+    wb = _bytes_or_raise(lib().n3dt_mlp_points_workspace_bytes(ctypes.byref(geom), M), "n3dt_mlp_points_workspace_bytes")
+    ws = WORKSPACE.get("seam_mlp", wb, vps.device)
+    check(lib().n3dt_mlp_points(ctypes.byref(geom), M, ctypes.byref(params), _ptr(aud), _ptr(vps), _ptr(vds), _ptr(rgb), _ptr(dens),
+                                _ptr(ws), wb, _stream()), "n3dt_mlp_points")
+    return rgb, dens
+
+
+def composite(rgb, density, z_dists, zvals):
+    """CalcRayColor.forward: (feat [B,C,Nr], bg_alpha [B,1,Nr], depth [B,1,Nr], weight [B,1,Nr,Ns])."""
+    rgb, density, z_dists, zvals = _f32c(rgb), _f32c(density), _f32c(z_dists), _f32c(zvals)
+    B, C, Nr, Ns = rgb.shape
+    dev = rgb.device
+    feat = torch.empty(B, C, Nr, dtype=torch.float32, device=dev)
+    ba = torch.empty(B, 1, Nr, dtype=torch.float32, device=dev)
+    dp = torch.empty(B, 1, Nr, dtype=torch.float32, device=dev)
+    w = torch.empty(B, 1, Nr, Ns, dtype=torch.float32, device=dev)
+    check(lib().n3dt_composite(B, Nr, Ns, C, _ptr(rgb), _ptr(density), _ptr(z_dists), _ptr(zvals), _ptr(feat), _ptr(ba), _ptr(dp), _ptr(w),
+                               _stream()), "n3dt_composite")
+    return feat, ba, dp, w
+
+
 def neural_render_fwd(geom, nb, rparams, featmap, precision=0):
     """featmap [nb, fs, fs, C] (ray-major) -> img [nb, 3, P, P]"""
     dev = featmap.device

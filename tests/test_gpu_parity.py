@@ -316,3 +316,39 @@ def test_hierarchical_pass(name, precision):
     assert np.abs(coarse - g["coarse_merge_img_q16"].astype(np.float32) / 65535.0).max() <= RGB_TOL[precision]
     assert np.abs(fine - g["fine_merge_img_q16"].astype(np.float32) / 65535.0).max() <= tol
     assert out["fine_dict"]["bg_img"].shape == (1, 3, opt.pred_img_size, opt.pred_img_size)
+
+
+def test_inner_seams_as_standalone_operators():
+    """sample_func, vp_encoder, fg_CD_predictor and calc_color_func stay addressable with the reference's
+    signatures.  Each stand-alone operator against the vectors the reference's own sub-modules produced (tiny_test), chained
+    the way HeadNeRFNet.calc_color_with_code chains them (HeadNeRFNet.py:84-101)."""
+    g, m = load_golden("tiny_test")
+    opt, sd, inp = synthetic_case(m)
+    net = build_net(opt, sd)
+    d = to_dev(inp)
+    B, n_r, ns = m["batch"], opt.featmap_size ** 2, opt.num_sample_coarse
+    s = net.sample_func(d["batch_xy"], d["batch_Rmats"], d["batch_Tvecs"], d["batch_inv_inmats"], False)
+    assert set(s.keys()) == {"pts", "dirs", "zvals", "z_dists", "batch_ray_o", "batch_ray_d", "batch_ray_l"}
+    np.testing.assert_allclose(s["pts"].cpu().numpy(), g["pts"], atol=2e-6)
+    np.testing.assert_allclose(s["z_dists"].cpu().numpy(), g["z_dists"], atol=2e-6)
+    np.testing.assert_allclose(s["zvals"].cpu().numpy(), g["zvals"], atol=2e-6)
+    np.testing.assert_allclose(s["batch_ray_d"].cpu().numpy()[..., 0], g["ray_d"], atol=2e-7)
+    assert s["dirs"].shape == (B, 3, n_r, ns) and s["batch_ray_o"].shape == (B, 3, n_r, 1)
+    pe = net.vp_encoder(torch.from_numpy(g["pts"]).to(dev()))
+    np.testing.assert_allclose(pe.cpu().numpy(), g["pe"], atol=1e-6)
+
+    def ex(code):
+        return code.unsqueeze(-1).unsqueeze(-1).expand(-1, -1, n_r, ns)
+    vps = torch.cat([torch.from_numpy(g["pe"]).to(dev()), ex(d["shape_code"])], dim=1)
+    rgb, dens = net.fg_CD_predictor(ex(d["audiostyle"]), vps, ex(d["appea_code"]))
+    np.testing.assert_allclose(dens.cpu().numpy(), g["density"], atol=2e-5)
+    np.testing.assert_allclose(rgb.cpu().numpy(), g["feat"], atol=2e-5)
+    feat, ba, dp, w = net.calc_color_func(s["pts"], torch.from_numpy(g["feat"]).to(dev()), torch.from_numpy(g["density"]).to(dev()),
+                                          torch.from_numpy(g["z_dists"]).to(dev()), torch.from_numpy(g["zvals"]).to(dev()))
+    np.testing.assert_allclose(feat.cpu().numpy(), g["fg_feat"], atol=2e-5)
+    np.testing.assert_allclose(ba.cpu().numpy(), g["bg_alpha"], atol=2e-5)
+    np.testing.assert_allclose(w.cpu().numpy(), g["weight"], atol=2e-5)
+    np.testing.assert_allclose(dp.cpu().numpy(), g["depth"], atol=4e-4)
+    # and the chain reproduces the fused call
+    f = feats(net, d)
+    np.testing.assert_allclose(feat.cpu().numpy(), f["fg_feat"].permute(0, 2, 1).cpu().numpy(), atol=3e-5)
