@@ -225,6 +225,11 @@ int n3dt_neural_render_bwd(const N3dtGeom* g, int nb, int precision, const N3dtR
                            const float* featmap, const float* d_img, const void* saved, size_t saved_bytes,
                            float* d_featmap, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- display conversion ----------------------------------------------------------------------------
+ * Replaces `(img.permute(1,2,0).numpy() * 255).astype(np.uint8)` (talker_trainer.py:1205, Utils/RenderUtils.py:123-125):
+ *   img [n_images,3,pixels] float in (0,1)  ->  out [n_images,pixels,3] uint8 */
+int n3dt_img_to_uint8(int n_images, int pixels, const float* img, unsigned char* out, void* stream);
+
 /* ---- fused loss tail -----------------------------------------------------------------
  * The three MSE data terms of the reference's loss (Utils/HeadNeRFLossUtils.py:125-146: bg_loss, head_loss,
  * nonhead_loss, including its nan_to_num) in one pass, and their gradient in one more; replaces three boolean-mask

@@ -79,6 +79,23 @@ __global__ void loss_tail_bwd_kernel(int B, int HW, const float* __restrict__ me
     }
 }
 
+// display conversion (talker_trainer.py:1205, Utils/RenderUtils.py:123-125): planar float [V,3,HW] in (0,1) ->
+// interleaved uint8 [V,HW,3], (unsigned char)(x * 255) like numpy's astype(np.uint8) on in-range values
+__global__ void img_to_uint8_kernel(int V, int HW, const float* __restrict__ img, unsigned char* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)V * HW) return;
+    const size_t v = i / HW, p = i % HW;
+    const float* src = img + v * 3 * (size_t)HW + p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float x = fminf(fmaxf(src[(size_t)c * HW] * 255.0f, 0.0f), 255.0f);
+        out[i * 3 + c] = (unsigned char)x;
+    }
+}
+extern "C" void n3dt_launch_img_to_uint8(int V, int HW, const float* img, unsigned char* out, hipStream_t s) {
+    hipLaunchKernelGGL(img_to_uint8_kernel, dim3((unsigned)(((size_t)V * HW + 255) / 256)), dim3(256), 0, s, V, HW, img, out);
+}
+
 extern "C" void n3dt_launch_loss_fwd(int B, int HW, const float* merge, const float* bg, const float* gt, const float* mask, float v,
                                      float* acc, float* terms, hipStream_t s) {
     (void)hipMemsetAsync(acc, 0, 6 * sizeof(float), s);

@@ -49,6 +49,7 @@ void n3dt_launch_train16_fwd(const N3dtGeom*, const N3dtMlpParams*, const void*,
 void n3dt_launch_train16_bwd(const N3dtGeom*, const N3dtMlpParams*, const N3dtMlpGrads*, const float*, const float*, const float*,
                              const float*, const float*, const float*, const float*, const void*, float*, float*, float*, float*,
                              const float*, const float*, const float*, const float*, const float*, float*, float*, void*, hipStream_t);
+void n3dt_launch_img_to_uint8(int, int, const float*, unsigned char*, hipStream_t);
 void n3dt_launch_loss_fwd(int, int, const float*, const float*, const float*, const float*, float, float*, float*, hipStream_t);
 void n3dt_launch_loss_bwd(int, int, const float*, const float*, const float*, const float*, float, const float*, const float*, float*,
                           float*, hipStream_t);
@@ -422,6 +423,12 @@ extern "C" int n3dt_neural_render_bwd(const N3dtGeom* g, int nb, int precision, 
     if (workspace_bytes < n3dt_neural_render_train_workspace_bytes(g, nb)) return fail(N3DT_EWORKSPACE, "neural render workspace too small");
     n3dt_launch_nr_bwd(g, nb, p, grads, featmap, d_img, (const float*)saved, d_featmap, (float*)workspace, precision == N3DT_BF16, (hipStream_t)stream);
     return check_hip("n3dt_neural_render_bwd");
+}
+
+extern "C" int n3dt_img_to_uint8(int n_images, int pixels, const float* img, unsigned char* out, void* stream) {
+    if (n_images < 1 || pixels < 1 || !img || !out) return fail(N3DT_EINVAL, "n3dt_img_to_uint8: bad argument");
+    n3dt_launch_img_to_uint8(n_images, pixels, img, out, (hipStream_t)stream);
+    return check_hip("n3dt_img_to_uint8");
 }
 
 extern "C" int n3dt_loss_fwd(int batch, int pixels, const float* merge_img, const float* bg_img, const float* gt, const float* mask,

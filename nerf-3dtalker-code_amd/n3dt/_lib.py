@@ -49,7 +49,7 @@ EXPORTS = [
     "n3dt_render_train_saved_bytes", "n3dt_render_train_workspace_bytes", "n3dt_render_train_fwd", "n3dt_render_bwd",
     "n3dt_neural_render_train_saved_bytes", "n3dt_neural_render_train_workspace_bytes",
     "n3dt_neural_render_train_fwd", "n3dt_neural_render_bwd", "n3dt_loss_fwd", "n3dt_loss_bwd", "n3dt_fine_sample",
-    "n3dt_sample_points", "n3dt_embed", "n3dt_mlp_points_workspace_bytes", "n3dt_mlp_points", "n3dt_composite",
+    "n3dt_img_to_uint8", "n3dt_sample_points", "n3dt_embed", "n3dt_mlp_points_workspace_bytes", "n3dt_mlp_points", "n3dt_composite",
 ]
 
 _LIB = None
@@ -111,6 +111,8 @@ def lib():
     L.n3dt_prof_collect.argtypes = [ctypes.POINTER(ctypes.c_float), ci, ctypes.POINTER(ci)]
     L.n3dt_fine_sample.restype = ci
     L.n3dt_fine_sample.argtypes = [gp, ci, vp, vp, vp, vp, vp, vp]
+    L.n3dt_img_to_uint8.restype = ci
+    L.n3dt_img_to_uint8.argtypes = [ci, ci, vp, vp, vp]
     L.n3dt_sample_points.restype = ci
     L.n3dt_sample_points.argtypes = [gp] + [vp] * 10 + [vp]
     L.n3dt_embed.restype = ci

@@ -129,6 +129,15 @@ def fine_sample(geom, n_fine, weight, T, t_rand=None, u=None):
     return z
 
 
+def img_to_uint8(img):
+    """[V,3,P,P] float in (0,1) -> [V,P,P,3] uint8 on the device (the reference's display conversion)."""
+    img = _f32c(img)
+    V, _, P, Q = img.shape
+    out = torch.empty(V, P, Q, 3, dtype=torch.uint8, device=img.device)
+    check(lib().n3dt_img_to_uint8(V, P * Q, _ptr(img), _ptr(out), _stream()), "n3dt_img_to_uint8")
+    return out
+
+
 # ---- the reference's inner seams as stand-alone operators (csrc/seams.hip) -------------------------------------
 def sample_points(geom, xy, R, T, Kinv, t_rand=None):
     """GenSamplePoints.forward: dict of pts [B,3,Nr,Ns], zvals / z_dists [B,1,Nr,Ns], ray_d [B,3,Nr], ray_l [B,1,Nr]."""

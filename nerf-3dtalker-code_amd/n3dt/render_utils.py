@@ -12,6 +12,8 @@ import math
 
 import torch
 
+from . import ops
+
 from . import synthetic
 
 
@@ -67,7 +69,7 @@ class RenderUtils(object):
     @staticmethod
     def _to_uint8_list(img):
         """[V,3,P,P] in (0,1) -> list of HxWx3 uint8 arrays, as the reference returns them (RenderUtils.py:123-125)."""
-        arr = (img.detach() * 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+        arr = ops.img_to_uint8(img.detach()).cpu().numpy()
         return [arr[i] for i in range(arr.shape[0])]
 
     def _audio(self, code_info, n):

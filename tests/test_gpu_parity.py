@@ -256,6 +256,17 @@ def test_error_behaviour():
                                 c["batch_Tvecs"], c["batch_inv_inmats"])
 
 
+def test_display_conversion_matches_numpy():
+    """n3dt_img_to_uint8 against the reference's expression `(img.permute(1,2,0).numpy() * 255).astype(np.uint8)`."""
+    from n3dt import ops
+    gen = torch.Generator().manual_seed(0)
+    img = torch.rand(3, 3, 40, 24, generator=gen)
+    img[0, 0, 0, :4] = torch.tensor([0.0, 1.0 / 255.0, 254.999 / 255.0, 0.5])
+    got = ops.img_to_uint8(img.to(dev())).cpu().numpy()
+    ref = (img.permute(0, 2, 3, 1).numpy() * 255).astype(np.uint8)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
 def test_novel_view_sweep_is_one_batched_render():
     """45 orbit views in ONE launch equal the reference-style 45 serial batch-1 renders, bit for bit."""
     from n3dt import BaseOptions, synthetic as syn
