@@ -85,18 +85,23 @@ def test_tiny_all_seams(name, precision):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
-@pytest.mark.parametrize("name", ["cfg1", "cfg2r", "hr"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2r", "hr", "cfg4"])
 def test_baseline_configs(name, precision):
-    """BASELINE configs 1, 2 (reading R) and the 1024^2 HR path (5 upsample stages, 96 samples/ray)."""
+    """BASELINE configs 1, 2 (reading R), the 1024^2 HR path (5 upsample stages, 96 samples/ray) and config 4's geometry
+    (4 heads, 256^2, 64 samples) in train mode (stratified jitter replayed from the fixture's seed)."""
+    from n3dt import synthetic as syn
     g, m = load_golden(name)
     opt, sd, inp = synthetic_case(m)
     net = build_net(opt, sd, precision)
     d = to_dev(inp)
-    f = feats(net, d)
+    t_rand = None
+    if m.get("mode") == "train":
+        t_rand = syn.stratified_noise(m["batch"], opt.featmap_size ** 2, opt.num_sample_coarse, m["t_rand_seed"]).to(dev())
+    f = feats(net, d, t_rand)
     step = int(g["ray_index_step"])
     np.testing.assert_allclose(f["fg_feat"].permute(0, 2, 1).cpu().numpy()[:, :, ::step], g["fg_feat"], atol=FEAT_TOL[precision])
     np.testing.assert_allclose(f["bg_alpha"].cpu().numpy()[:, None], g["bg_alpha"], atol=FEAT_TOL[precision])
-    out = fwd(net, d)
+    out = fwd(net, d, m.get("mode", "test"), t_rand)
     img = out["merge_img"].cpu().numpy()
     bg = out["bg_img"].cpu().numpy()
     tol = RGB_TOL[precision]

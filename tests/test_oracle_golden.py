@@ -157,3 +157,17 @@ def test_hierarchical_pass(name):
     np.testing.assert_allclose(out["fine_bg_alpha"], g["fine_bg_alpha"], atol=5e-4)
     assert np.abs(out["coarse_merge_img"] - g["coarse_merge_img_q16"].astype(np.float32) / 65535.0).max() <= 1e-4
     assert np.abs(out["fine_merge_img"] - g["fine_merge_img_q16"].astype(np.float32) / 65535.0).max() <= 1e-3
+
+
+def test_forward_cfg4_train_mode():
+    """BASELINE config 4's geometry (4 heads, fs 32, 64 samples, 256^2) in train mode: the stratified jitter is replayed
+    from the fixture's seed (the reference consumed the same tensor through torch.rand_like, NetWorks/utils.py:77)."""
+    from n3dt import synthetic as syn
+    g, m = load_golden("cfg4")
+    opt, sd, inp = synthetic_case(m)
+    t_rand = t2n(syn.stratified_noise(m["batch"], opt.featmap_size ** 2, opt.num_sample_coarse, m["t_rand_seed"]))
+    out = orc.forward(sd, opt, inp, t_rand)
+    step = int(g["ray_index_step"])
+    np.testing.assert_allclose(out["fg_feat"][:, :, ::step], g["fg_feat"], atol=3e-4)
+    np.testing.assert_allclose(out["bg_alpha"], g["bg_alpha"], atol=1e-4)
+    assert np.abs(out["merge_img"] - g["merge_img_q16"].astype(np.float32) / 65535.0).max() <= 1e-3

@@ -221,13 +221,14 @@ def gen_tiny(HeadNeRFNet, mode):
     }))
 
 
-def gen_cfg(HeadNeRFNet, name, fs, ns, pred, ray_step, B=1, crop=None):
+def gen_cfg(HeadNeRFNet, name, fs, ns, pred, ray_step, B=1, crop=None, mode="test"):
     opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": pred, "num_sample_coarse": ns})
     sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
     net = build_ref_net(HeadNeRFNet, opt, sd)
     inp = syn.frame_inputs(opt, B, yaw_range=0.3)
+    t_rand = syn.stratified_noise(B, fs * fs, ns, 7) if mode == "train" else None
     with torch.no_grad():
-        coarse, s = run_seams(net, inp, "test")
+        coarse, s = run_seams(net, inp, mode, t_rand)
     rays = slice(0, fs * fs, ray_step)
     samp = s["sample"]
     img = np32(coarse["merge_img"])
@@ -255,7 +256,7 @@ def gen_cfg(HeadNeRFNet, name, fs, ns, pred, ray_step, B=1, crop=None):
         arrays["merge_img_crop_q16"] = q16(img[:, :, c0:c0 + crop, c0:c0 + crop])
         arrays["crop_origin"] = np.int64(c0)
     save(name, arrays, manifest_base(name, opt, {
-        "batch": B, "mode": "test", "weights_seed": 0, "bg_noise": 0.1, "yaw_range": 0.3,
+        "batch": B, "mode": mode, "t_rand_seed": 7, "weights_seed": 0, "bg_noise": 0.1, "yaw_range": 0.3,
         "weights_checksum": syn.state_dict_checksum(sd),
     }))
 
@@ -408,6 +409,7 @@ def main():
         "cfg1": lambda: gen_cfg(HeadNeRFNet, "cfg1", fs=32, ns=32, pred=256, ray_step=16),
         "cfg2r": lambda: gen_cfg(HeadNeRFNet, "cfg2r", fs=64, ns=64, pred=512, ray_step=64),
         "hr": lambda: gen_cfg(HeadNeRFNet, "hr", fs=32, ns=96, pred=1024, ray_step=16, crop=256),
+        "cfg4": lambda: gen_cfg(HeadNeRFNet, "cfg4", fs=32, ns=64, pred=256, ray_step=16, B=4, mode="train"),
         "hier_test": lambda: gen_hier(HeadNeRFNet, "hier_test", fs=8, nc=64, nf=128, pred=32, B=1, mode="test"),
         "hier_train": lambda: gen_hier(HeadNeRFNet, "hier_train", fs=8, nc=16, nf=24, pred=32, B=2, mode="train"),
     }
