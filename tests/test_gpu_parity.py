@@ -115,23 +115,28 @@ def test_baseline_configs(name, precision):
     np.testing.assert_allclose(bg.astype(np.float64).sum(-1), g["bg_img_rowsum"], atol=(1e-5 if precision == "fp32" else tol) * bg.shape[-1])
 
 
-def test_variants_gaze_and_no_audio():
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+def test_variants_gaze_and_no_audio(precision):
+    """include_gaze=True (eye_gaze_dim 64 wider shape code) and the audio-less *_yuan network, against the reference's own
+    outputs for those modules, in every render precision (the latent widths change the folded biases and the packing)."""
     g, m = load_golden("edges")
     from n3dt import synthetic as syn
     opt = options_from_manifest(m)
+    ft = 2e-5 if precision == "fp32" else FEAT_TOL[precision]
+    rt = 1e-4 if precision == "fp32" else RGB_TOL[precision]
     sdg = syn.make_state_dict(opt, seed=3, include_gaze=True, eye_gaze_dim=64, bg_noise=0.1)
-    net = build_net(opt, sdg, include_gaze=True, eye_gaze_dim=64)
+    net = build_net(opt, sdg, precision, include_gaze=True, eye_gaze_dim=64)
     d = to_dev(syn.frame_inputs(opt, 1, include_gaze=True, eye_gaze_dim=64))
     f = feats(net, d)
-    np.testing.assert_allclose(f["fg_feat"].permute(0, 2, 1).cpu().numpy(), g["gaze.fg_feat"], atol=2e-5)
-    assert np.abs(fwd(net, d)["merge_img"].cpu().numpy() - g["gaze.merge_img"]).max() <= 1e-4
+    np.testing.assert_allclose(f["fg_feat"].permute(0, 2, 1).cpu().numpy(), g["gaze.fg_feat"], atol=ft)
+    assert np.abs(fwd(net, d)["merge_img"].cpu().numpy() - g["gaze.merge_img"]).max() <= rt
     sdn = syn.make_state_dict(opt, seed=4, audio_dim=0, bg_noise=0.1)
-    netn = build_net(opt, sdn, audio_dim=0)
+    netn = build_net(opt, sdn, precision, audio_dim=0)
     dn = to_dev(syn.frame_inputs(opt, 1, audio_dim=0))
     dn["audiostyle"] = None
     f = feats(netn, dn)
-    np.testing.assert_allclose(f["fg_feat"].permute(0, 2, 1).cpu().numpy(), g["noaudio.fg_feat"], atol=2e-5)
-    assert np.abs(fwd(netn, dn)["merge_img"].cpu().numpy() - g["noaudio.merge_img"]).max() <= 1e-4
+    np.testing.assert_allclose(f["fg_feat"].permute(0, 2, 1).cpu().numpy(), g["noaudio.fg_feat"], atol=ft)
+    assert np.abs(fwd(netn, dn)["merge_img"].cpu().numpy() - g["noaudio.merge_img"]).max() <= rt
 
 
 def test_neural_render_seam():
