@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The built libraries are git-ignored: a fresh checkout compiles them once (hipcc cross-compiles gfx950 without a GPU).
+    Nothing is built when they are already there (the GPU box receives them with the snapshot)."""
+    import shutil
+    import subprocess
+    lib = os.path.join(REPO, "nerf-3dtalker-code_amd", "lib", "libn3dt.so")
+    if not os.path.exists(lib) and shutil.which("make") and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        subprocess.check_call(["make", "-s", "-j", str(min(8, os.cpu_count() or 1)), "-C", os.path.join(REPO, "nerf-3dtalker-code_amd")])
+
+
 def load_golden(name):
     data = np.load(os.path.join(GOLDEN, name + ".npz"))
     with open(os.path.join(GOLDEN, name + ".json")) as f:
