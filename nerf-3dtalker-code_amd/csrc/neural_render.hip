@@ -205,7 +205,7 @@ static NrCarve nr_carve(const N3dtGeom* g, int nb) {
     c.bl = c.ps;
     size_t P = (size_t)g->featmap_size << g->n_blocks;
     c.rgb = (size_t)nb * 3 * P * P;
-    c.total = c.t1 + c.ps + c.bl + 2 * c.net + 2 * c.rgb;
+    c.total = c.t1 + c.ps + c.bl + 2 * c.net + 2 * c.rgb + nrf_pack_floats(g);
     return c;
 }
 

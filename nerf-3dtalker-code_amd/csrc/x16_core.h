@@ -145,7 +145,34 @@ __device__ __forceinline__ unsigned long long x16_now() {
 #define X16_T(x)
 #endif
 
-template <int PREC, int WAVES, int NCHUNK = X16_NCHUNK>
+// The counted fragment waits of the weight stream (s_waitcnt lgkmcnt(DEPTH-1)) rely on LDS operations returning in
+// order.  Scalar memory loads share that counter and return OUT of order: one s_load outstanding next to a fragment read
+// lets the wait pass on the wrong completion.  hipcc loads kernel arguments lazily, at their first use, which can be in
+// the middle of the stream (seen: the output pointer of the fused renderer block, two arguments of the camera-gradient
+// backward kernel).  A kernel that uses the stream therefore passes every argument it needs after the prologue through
+// x16_pin() before WeightStream::prologue_wait(): the empty asm forces the load up there, and its opaque result cannot be
+// re-fetched from the argument segment later.  tools/check_smem_hazard.py scans the generated code for violations.
+// (pointers travel through the asm as integers and come back as global-address-space pointers: an opaque generic
+// pointer would turn every access through it into a flat_ instruction, which counts on BOTH wait counters)
+template <class T>
+__device__ __forceinline__ void x16_pin(T& v) {
+    static_assert(sizeof(T) <= 8, "scalar register pair at most");
+    asm volatile("" : "+s"(v));
+}
+template <class T>
+__device__ __forceinline__ void x16_pin(T*& p) {
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+s"(v));
+    p = (T*)(GLOBAL_AS T*)v;
+}
+template <class T>
+__device__ __forceinline__ void x16_pin_v(T*& p) {  // per-lane pointers
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+v"(v));
+    p = (T*)(GLOBAL_AS T*)v;
+}
+
+template <int PREC, int WAVES, int NCHUNK = X16_NCHUNK, int NBUF = X16_NBUF>
 struct WeightStream {
     X16_T(unsigned long long t_rv = 0; unsigned long long t_mfma = 0; unsigned long long t_epi = 0; unsigned long long t_bias = 0;
           int tile_no = 0; float* tl = nullptr;)
@@ -162,18 +189,19 @@ struct WeightStream {
 
     __device__ __forceinline__ void issue(int c) {
         const unsigned char* src = gsrc + (size_t)c * X16_CHUNK_BYTES;
-        unsigned char* dst = ring + (c % X16_NBUF) * X16_CHUNK_BYTES + wave * PPW * X16_PIECE;
+        unsigned char* dst = ring + (c % NBUF) * X16_CHUNK_BYTES + wave * PPW * X16_PIECE;
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + i * X16_PIECE), (LDS_AS void*)(dst + i * X16_PIECE), 16, 0,
                                              0);
     }
     __device__ __forceinline__ void prologue_issue() {
-        issue(0);
-        issue(1);
+#pragma unroll
+        for (int i = 0; i < NBUF - 1; ++i)
+            if (i < NCHUNK) issue(i);
     }
     __device__ __forceinline__ void prologue_wait() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         chunk = 0;
         meets = 0;
@@ -188,10 +216,17 @@ struct WeightStream {
             preload<J + 1>();
         }
     }
+    // NBUF > 3 (a deeper ring: chunk meets+1 was issued NBUF-2 rendezvous ago) only needs the loads OLDER than the
+    // newest (NBUF-3) chunks to have landed: loads return in order, so "at most (NBUF-3)*PPW operations outstanding"
+    // is enough (stores in the count only make the wait more conservative) -- while newer chunks are in flight behind
+    // it, i.e. until the stream's tail.
     __device__ __forceinline__ void rendezvous() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk meets+1 have landed
-        __syncthreads();                                   // everyone's have; everyone has left chunk meets-1
-        if (meets + 2 < NCHUNK) issue(meets + 2);
+        if (NBUF > 3 && meets + NBUF - 2 < NCHUNK) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NBUF - 3) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk meets+1 have landed
+        __syncthreads();                                                          // everyone's have; everyone has left chunk meets-1
+#ifndef X16_NODMA  // diagnostic build: the stream stops after the prologue (results are garbage, the timing is the point)
+        if (meets + NBUF - 1 < NCHUNK) issue(meets + NBUF - 1);
+#endif
         ++meets;
     }
     // The fragment reads are issued from inline asm so that their completion can be awaited with a COUNTED
@@ -218,6 +253,10 @@ struct WeightStream {
             X16_T(t_rv += x16_now() - r0;)
         }
         constexpr int Q = P + X16_DEPTH - 1;
+#ifdef X16_NOLDS  // diagnostic build: no fragment reads at all (garbage results)
+        if ((P + 1) % X16_CH == 0) ++chunk;
+        return a[0];
+#endif
         if (!(LAST && Q >= NP)) {
             const unsigned addr = (Q % X16_CH < P % X16_CH) ? nxt_addr : cur_addr;
             read_frag<(Q % X16_CH) * X16_PIECE>(a[Q % X16_DEPTH], addr);
@@ -227,7 +266,7 @@ struct WeightStream {
         if ((P + 1) % X16_CH == 0) {
             ++chunk;
             cur_addr = nxt_addr;
-            nxt_addr = lds_addr0 + ((chunk + 1) % X16_NBUF) * X16_CHUNK_BYTES;
+            nxt_addr = lds_addr0 + ((chunk + 1) % NBUF) * X16_CHUNK_BYTES;
         }
         return r;
     }
