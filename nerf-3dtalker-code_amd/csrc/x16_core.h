@@ -145,6 +145,16 @@ __device__ __forceinline__ unsigned long long x16_now() {
 #define X16_T(x)
 #endif
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N) -- the piece index has to reach the
+// inline-asm immediates as a constant expression
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 // The counted fragment waits of the weight stream (s_waitcnt lgkmcnt(DEPTH-1)) rely on LDS operations returning in
 // order.  Scalar memory loads share that counter and return OUT of order: one s_load outstanding next to a fragment read
 // lets the wait pass on the wrong completion.  hipcc loads kernel arguments lazily, at their first use, which can be in
@@ -190,6 +200,8 @@ struct WeightStream {
     __device__ __forceinline__ void issue(int c) {
         const unsigned char* src = gsrc + (size_t)c * X16_CHUNK_BYTES;
         unsigned char* dst = ring + (c % NBUF) * X16_CHUNK_BYTES + wave * PPW * X16_PIECE;
+        // (the instruction's immediate offset is not used: with one M0 and offsets 0 / 1 KiB / 2 KiB, and with a per-piece
+        // M0 plus the offset on top, the fused kernel's results were wrong -- its effect on the LDS address was not pinned down)
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + i * X16_PIECE), (LDS_AS void*)(dst + i * X16_PIECE), 16, 0,
@@ -293,15 +305,6 @@ __device__ __forceinline__ float pe_fast(const float p0, const float p1, const f
 
 enum { MODE_HIDDEN = 0, MODE_LINEAR = 1, MODE_DENSITY = 2, MODE_COMPOSITE = 3 };
 
-// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N) -- the piece index has to reach the
-// inline-asm immediates as a constant expression
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 // sum over the 32 lanes of a half-wave of 32 per-lane values: lane c ends with value index rev5(c)
 __device__ __forceinline__ float butterfly32(float (&v)[32], const int c) {
