@@ -6,6 +6,8 @@ Tolerances (floating point, stated per BASELINE.json north_star):
   bf16 / f16 : measured RGB L-inf <= 5.4e-4 / 9.2e-5 on the fixtures; asserted at 1e-3 (the north-star gate itself,
                so the headline bf16 mode is held to it too) / 5e-4.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -373,3 +375,23 @@ def test_inner_seams_as_standalone_operators():
     # and the chain reproduces the fused call
     f = feats(net, d)
     np.testing.assert_allclose(feat.cpu().numpy(), f["fg_feat"].permute(0, 2, 1).cpu().numpy(), atol=3e-5)
+
+
+@pytest.mark.gpu
+def test_fused_renderer_blocks_against_layered_path(tmp_path):
+    """The 16-bit renderer's fused block kernel (csrc/nr_fused_x16.inc) against the layered GEMM path it replaced
+    (N3DT_NR_FUSED=0; the switch is read once per process, hence the two child processes), on a 16^2 -> 256^2 geometry
+    whose four blocks cover every block size the fused kernel is built for (C = 256, 128, 64, 32)."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "nr_fused_check.py")
+    ref, fused = str(tmp_path / "layered.npy"), str(tmp_path / "fused.npy")
+    env = dict(os.environ, N3DT_NR_FUSED="0")
+    subprocess.run([sys.executable, tool, "16", "256", "2", ref], check=True, env=env, timeout=300)
+    env = dict(os.environ, N3DT_NR_FUSED="1")
+    out = subprocess.run([sys.executable, tool, "16", "256", "2", fused, ref], check=True, env=env, timeout=300,
+                         capture_output=True, text=True).stdout
+    a, b = np.load(ref), np.load(fused)
+    assert a.shape == (2, 3, 256, 256) and np.isfinite(b).all(), out
+    # both are bf16 renderings of the same fp32 network: they differ by rounding only, well inside the 1e-3 gate
+    assert np.abs(a - b).max() <= 1e-3, out

@@ -133,3 +133,20 @@ def test_checkpoint_round_trip_and_gaze_extension(tmp_path):
     assert w.shape[1] == 306 + 64 and float(w[:, 306:].abs().max()) == 0.0
     skipped = checkpoint.load_ckpt(net2, {"fg_CD_predictor.RGB_layer_2.bias": torch.zeros(256), "bogus": torch.zeros(1)})
     assert skipped == ["bogus"] and float(net2.state_dict()["fg_CD_predictor.RGB_layer_2.bias"].abs().max()) == 0.0
+
+
+def test_stream_hazard_scanner_flags_scalar_and_flat_accesses(tmp_path):
+    """tools/check_smem_hazard.py: a scalar or flat access after the first inline-asm fragment read of a kernel is a
+    finding (the counted lgkmcnt waits of the weight stream assume in-order LDS returns only); before it, it is not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_smem_hazard", os.path.join(REPO, "tools", "check_smem_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    clean = "_Z1kv:\n\ts_load_dwordx2 s[0:1], s[0:1], 0x0\n\t;;#ASMSTART\n\tds_read_b128 v[0:3], v4 offset:0\n\t;;#ASMEND\n\tv_mfma_f32_32x32x16_bf16 a[0:15], v[0:3], v[4:7], a[0:15]\n\ts_endpgm\n"
+    late = clean.replace("\tv_mfma", "\ts_load_dwordx2 s[2:3], s[0:1], 0x18\n\tv_mfma")
+    flat = clean.replace("\tv_mfma", "\tflat_load_dword v9, v[10:11]\n\tv_mfma")
+    for name, text, n in (("clean", clean, 0), ("late", late, 1), ("flat", flat, 1)):
+        f = tmp_path / (name + ".s")
+        f.write_text(text)
+        found = mod.scan(str(f))
+        assert len(found) == n, (name, found)
