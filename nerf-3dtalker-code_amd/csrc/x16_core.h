@@ -155,13 +155,15 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// The counted fragment waits of the weight stream (s_waitcnt lgkmcnt(DEPTH-1)) rely on LDS operations returning in
-// order.  Scalar memory loads share that counter and return OUT of order: one s_load outstanding next to a fragment read
-// lets the wait pass on the wrong completion.  hipcc loads kernel arguments lazily, at their first use, which can be in
-// the middle of the stream (seen: the output pointer of the fused renderer block, two arguments of the camera-gradient
-// backward kernel).  A kernel that uses the stream therefore passes every argument it needs after the prologue through
-// x16_pin() before WeightStream::prologue_wait(): the empty asm forces the load up there, and its opaque result cannot be
-// re-fetched from the argument segment later.  tools/check_smem_hazard.py scans the generated code for violations.
+// Keeping scalar loads out of the stream.  The counted fragment waits (s_waitcnt lgkmcnt(DEPTH-1)) share their counter
+// with scalar memory loads, which return out of order.  That cannot make a wait pass EARLY -- the awaited fragment is the
+// oldest LDS operation in flight and LDS returns in order, so while it is outstanding the younger prefetch behind it is
+// too and the counter stays above DEPTH-1 whatever the scalar loads do -- but every stray s_load makes the wait longer
+// (it has to drain as well) and costs an issue slot in the MFMA stream.  hipcc fetches kernel arguments lazily, at their
+// first use, which can be deep inside the stream (seen: the output pointer of the fused renderer block, two arguments of
+// the camera-gradient backward kernel).  Such kernels pass what they need later through x16_pin() before
+// WeightStream::prologue_wait(): the empty asm forces the load up there and its opaque result cannot be re-fetched from
+// the argument segment.  tools/check_smem_hazard.py scans the generated code for scalar / flat accesses inside streams.
 // (pointers travel through the asm as integers and come back as global-address-space pointers: an opaque generic
 // pointer would turn every access through it into a flat_ instruction, which counts on BOTH wait counters)
 template <class T>
@@ -194,11 +196,19 @@ struct WeightStream {
     int chunk;                  // chunk of the piece being consumed
     int meets;                  // rendezvous done so far
     int wave;
+    // The stream can wrap around (prologue_issue(passes)): a persistent workgroup that walks several tiles keeps it running
+    // across them.  Tried for the render kernel and not kept: with the tile body inlined into a tile loop hipcc hoists the
+    // encoder's per-lane selectors and address constants out of the loop and spills (140 SGPR + 80 VGPR: 11.5 ms against
+    // 7.2); with the body as a noinline callee (uniform arguments moved to SGPRs on entry) it still spills 15 fragments
+    // (9.8 ms) -- the one-tile kernel sits at 254 of 256 registers and the loop adds a handful.  Results were correct.
+    int limit;                  // chunks to stage in all: passes * NCHUNK
+    int src_c;                  // source chunk of the next issue (wraps at NCHUNK: every pass streams the same weights)
     frag a[X16_DEPTH];          // piece p sits in a[p % X16_DEPTH]
     static constexpr int PPW = X16_CH / WAVES;  // pieces each wave stages per chunk
 
-    __device__ __forceinline__ void issue(int c) {
-        const unsigned char* src = gsrc + (size_t)c * X16_CHUNK_BYTES;
+    __device__ __forceinline__ void issue(int c) {  // c: chunk count since the prologue (picks the ring buffer)
+        const unsigned char* src = gsrc + (size_t)src_c * X16_CHUNK_BYTES;
+        src_c = src_c + 1 == NCHUNK ? 0 : src_c + 1;
         unsigned char* dst = ring + (c % NBUF) * X16_CHUNK_BYTES + wave * PPW * X16_PIECE;
         // (the instruction's immediate offset is not used: with one M0 and offsets 0 / 1 KiB / 2 KiB, and with a per-piece
         // M0 plus the offset on top, the fused kernel's results were wrong -- its effect on the LDS address was not pinned down)
@@ -207,11 +217,15 @@ struct WeightStream {
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + i * X16_PIECE), (LDS_AS void*)(dst + i * X16_PIECE), 16, 0,
                                              0);
     }
-    __device__ __forceinline__ void prologue_issue() {
+    __device__ __forceinline__ void prologue_issue(const int passes = 1) {
+        limit = passes * NCHUNK;
+        src_c = 0;
 #pragma unroll
         for (int i = 0; i < NBUF - 1; ++i)
-            if (i < NCHUNK) issue(i);
+            if (i < limit) issue(i);
     }
+    // a persistent workgroup is done: nothing of the stream may still be in flight towards its LDS when it exits
+    __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
     __device__ __forceinline__ void prologue_wait() {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
@@ -233,11 +247,11 @@ struct WeightStream {
     // is enough (stores in the count only make the wait more conservative) -- while newer chunks are in flight behind
     // it, i.e. until the stream's tail.
     __device__ __forceinline__ void rendezvous() {
-        if (NBUF > 3 && meets + NBUF - 2 < NCHUNK) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NBUF - 3) * PPW) : "memory");
+        if (NBUF > 3 && meets + NBUF - 2 < limit) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NBUF - 3) * PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk meets+1 have landed
         __syncthreads();                                                          // everyone's have; everyone has left chunk meets-1
 #ifndef X16_NODMA  // diagnostic build: the stream stops after the prologue (results are garbage, the timing is the point)
-        if (meets + NBUF - 1 < NCHUNK) issue(meets + NBUF - 1);
+        if (meets + NBUF - 1 < limit) issue(meets + NBUF - 1);
 #endif
         ++meets;
     }

@@ -137,7 +137,7 @@ def test_checkpoint_round_trip_and_gaze_extension(tmp_path):
 
 def test_stream_hazard_scanner_flags_scalar_and_flat_accesses(tmp_path):
     """tools/check_smem_hazard.py: a scalar or flat access after the first inline-asm fragment read of a kernel is a
-    finding (the counted lgkmcnt waits of the weight stream assume in-order LDS returns only); before it, it is not."""
+    finding (such accesses share the counter of the stream's counted lgkmcnt waits and only slow them down); before it, it is not."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("check_smem_hazard", os.path.join(REPO, "tools", "check_smem_hazard.py"))
     mod = importlib.util.module_from_spec(spec)

@@ -1,8 +1,10 @@
-"""Scan hipcc's gfx950 assembly of the stream kernels for scalar memory loads issued after the fragment stream has started.
+"""Scan hipcc's gfx950 assembly of the stream kernels for scalar / flat memory accesses issued after the fragment stream
+has started.
 
-The weight stream awaits its LDS fragment reads with COUNTED waits (s_waitcnt lgkmcnt(DEPTH-1), x16_core.h).  Scalar loads
-share that counter but return out of order, so one of them in flight next to a fragment read lets the wait pass early.
-hipcc fetches kernel arguments lazily; kernels pin what they need up front (x16_pin) and this script checks the result.
+The weight stream awaits its LDS fragment reads with COUNTED waits (s_waitcnt lgkmcnt(DEPTH-1), x16_core.h).  Scalar and
+flat accesses share that counter and return out of order: they cannot let a wait pass early (the awaited fragment is the
+oldest LDS operation in flight), but they lengthen the waits and take issue slots inside the MFMA stream.  hipcc fetches
+kernel arguments lazily; kernels pin what they need up front (x16_pin) and this script checks the result.
 
 usage: python tools/check_smem_hazard.py        (compiles the four sources to assembly, ~5 min; exit code 1 on a finding)
 """
