@@ -265,8 +265,9 @@ struct WeightStream {
     __device__ __forceinline__ void read_frag(frag& dst, const unsigned addr) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
     }
+    template <int YOUNGER = X16_DEPTH - 1>  // fragment reads issued after this one that may still be in flight
     __device__ __forceinline__ void await_frag(frag& f) {
-        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "i"(X16_DEPTH - 1));
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "i"(YOUNGER));
     }
     // Fragment of stage-local piece P (stages are whole chunks, so P % X16_CH and P % X16_DEPTH equal their
     // stream-global values).  LAST/NP: the final stage must not prefetch past the end of the stream.
@@ -287,7 +288,9 @@ struct WeightStream {
             const unsigned addr = (Q % X16_CH < P % X16_CH) ? nxt_addr : cur_addr;
             read_frag<(Q % X16_CH) * X16_PIECE>(a[Q % X16_DEPTH], addr);
         }
-        await_frag(a[P % X16_DEPTH]);
+        // at the stream's tail fewer reads are in flight behind this one: the count shrinks with them
+        constexpr int younger = (LAST && NP - 1 - P < X16_DEPTH - 1) ? NP - 1 - P : X16_DEPTH - 1;
+        await_frag<younger>(a[P % X16_DEPTH]);
         const frag r = a[P % X16_DEPTH];
         if ((P + 1) % X16_CH == 0) {
             ++chunk;
@@ -295,6 +298,16 @@ struct WeightStream {
             nxt_addr = lds_addr0 + ((chunk + 1) % NBUF) * X16_CHUNK_BYTES;
         }
         return r;
+    }
+    // A prefetch that nothing consumes must not be issued (LAST): its destination registers are dead to the compiler, which
+    // hands them to other values while the read is still in flight -- the data then lands on top of them (seen in the
+    // fused renderer block: store addresses overwritten by weight bytes, i.e. wild stores).  Where the code cannot know at
+    // compile time whether the stream continues (a rolled loop over passes: the value is loop-carried, so its registers
+    // stay reserved inside the loop), settle() after the loop retires the last prefetch before the registers are reused.
+    // A RUN-TIME condition around read_frag / await_frag is not an option: the branch makes the fragment a phi and hipcc
+    // copies the (not yet landed) registers ahead of the wait.
+    __device__ __forceinline__ void settle() {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[X16_DEPTH - 1]));
     }
 };
 
