@@ -51,7 +51,10 @@ __host__ __device__ inline size_t n3dt_packed_matrix_elems() { return n3dt_stage
 
 // the fp32 tail that follows the matrices in every precision: W2^T [192][256], b2 [256]
 // (+ the fp32 merged RGB matrix W_m [192][384] the 16-bit matrices are packed from)
-__host__ __device__ inline size_t n3dt_packed_tail_floats() { return (size_t)192 * 256 + 256 + (size_t)192 * 384; }
+// ... then the merged RGB matrix W_m [192][384] (fp32), and W2^T once more as bf16 hi + lo MFMA B fragments for the per-ray
+// head (n3dt_tail_w2_frags_offset: piece ((ks * 8 + tile) * 2 + part) of 1 KiB, lane-linear; part 0 = hi, 1 = lo)
+__host__ __device__ inline size_t n3dt_tail_w2_frags_offset() { return (size_t)192 * 256 + 256 + (size_t)192 * 384; }  // in floats
+__host__ __device__ inline size_t n3dt_packed_tail_floats() { return n3dt_tail_w2_frags_offset() + (size_t)12 * 8 * 2 * 256; }
 
 __host__ __device__ inline size_t n3dt_packed_elem_bytes(int precision) { return precision == 0 ? 4 : 2; }
 

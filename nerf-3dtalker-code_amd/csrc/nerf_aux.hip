@@ -135,6 +135,18 @@ __global__ void pack_tail_kernel(N3dtMlpParams p, float* __restrict__ tail) {
         tail[i] = p.weight[11][(size_t)c * N3DT_G + j];
     } else if (i < N3DT_G * N3DT_C + N3DT_C) {
         tail[i] = p.bias[11][i - N3DT_G * N3DT_C];
+    } else if (i < N3DT_G * N3DT_C + N3DT_C + 12 * 8 * 2 * 64) {
+        // B fragments of W2^T for the MFMA head: lane (column r31 of tile, k group h) holds k = 16 ks + 8 h + j, j = 0..7
+        const int t = i - (N3DT_G * N3DT_C + N3DT_C);
+        const int lane = t & 63, piece = t >> 6, part = piece & 1, tile = (piece >> 1) & 7, ks = piece >> 4;
+        const int col = 32 * tile + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
+        unsigned short* dst = reinterpret_cast<unsigned short*>(tail + n3dt_tail_w2_frags_offset()) + (size_t)piece * 512 + lane * 8;
+        for (int j = 0; j < 8; ++j) {
+            const float v = p.weight[11][(size_t)col * N3DT_G + k0 + j];
+            const __bf16 hi = (__bf16)v;
+            const __bf16 out = part == 0 ? hi : (__bf16)(v - (float)hi);
+            dst[j] = __builtin_bit_cast(unsigned short, out);
+        }
     }
 }
 
@@ -149,7 +161,7 @@ extern "C" void n3dt_launch_pack(const N3dtGeom* g, int precision, const N3dtMlp
     if (precision != N3DT_F32)
         hipLaunchKernelGGL(pack_mlp_kernel, dim3(64, N3DT_NSTAGE), dim3(256), 0, stream, *p, precision, 1, g->shape_dim, g->appea_dim,
                            g->audio_dim, wm, reinterpret_cast<unsigned char*>(packed) + n3dt_packed_region_b_offset(precision));
-    const int n = N3DT_G * N3DT_C + N3DT_C;
+    const int n = N3DT_G * N3DT_C + N3DT_C + 12 * 8 * 2 * 64;
     hipLaunchKernelGGL(pack_tail_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, *p, tail);
 }
 
@@ -355,7 +367,7 @@ __global__ __launch_bounds__(256) void ray_head_mfma_kernel(N3dtGeom g, int bpr,
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-    const float* W2T = tail;
+    const rh_bf16x8* w2frags = reinterpret_cast<const rh_bf16x8*>(tail + n3dt_tail_w2_frags_offset());
 #pragma unroll 2
     for (int ks = 0; ks < N3DT_G / 16; ++ks) {
         const int k0 = 16 * ks + 8 * h;
@@ -370,15 +382,10 @@ __global__ __launch_bounds__(256) void ray_head_mfma_kernel(N3dtGeom g, int bpr,
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int col = 64 * wave + 32 * i + r31;
-            rh_bf16x8 b_hi, b_lo;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float v = W2T[(size_t)(k0 + j) * N3DT_C + col];
-                const __bf16 hi = (__bf16)v;
-                b_hi[j] = hi;
-                b_lo[j] = (__bf16)(v - (float)hi);
-            }
+            // W2^T as pre-split bf16 hi / lo B fragments (pack_tail_kernel): two 16-byte loads instead of 8 strided
+            // dwords and their conversions per fragment
+            const rh_bf16x8* fr = w2frags + ((size_t)(ks * 8 + 2 * wave + i) * 2) * 64 + lane;
+            const rh_bf16x8 b_hi = fr[0], b_lo = fr[64];
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[i], 0, 0, 0);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[i], 0, 0, 0);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[i], 0, 0, 0);
