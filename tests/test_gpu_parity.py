@@ -203,13 +203,15 @@ def test_many_samples_per_ray_against_oracle(precision):
     np.testing.assert_allclose(w.sum(-1) + f["bg_alpha"].cpu().numpy(), 1.0, atol=1e-4 if precision == "fp32" else 5e-3)
 
 
+@pytest.mark.parametrize("fs", [12, 10])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_non_power_of_two_feature_map_against_oracle(precision):
-    """featmap_size 12 -> 48^2: the renderer's index math takes its general (division) path instead of shifts and masks,
-    and the ray count is not a multiple of the kernels' tile sizes."""
+def test_non_power_of_two_feature_map_against_oracle(precision, fs):
+    """featmap_size 12 -> 48^2 and 10 -> 40^2: the renderer's index math takes its general (division) path instead of
+    shifts and masks, and the ray count is not a multiple of the kernels' tile sizes (with 10, the 4 x 100 pixels of the
+    first renderer block end in the middle of a 32-pixel wavefront tile of the fused block kernel)."""
     from n3dt import BaseOptions, synthetic as syn
     from oracle import oracle as orc
-    opt = BaseOptions({"featmap_size": 12, "featmap_nc": 256, "pred_img_size": 48, "num_sample_coarse": 24})
+    opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": 4 * fs, "num_sample_coarse": 24})
     sd = syn.make_state_dict(opt, seed=9, bg_noise=0.2)
     inp = syn.frame_inputs(opt, 3, yaw_range=0.4, first_frame=11)
     ref = orc.forward(sd, opt, inp, None)
