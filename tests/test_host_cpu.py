@@ -150,3 +150,14 @@ def test_stream_hazard_scanner_flags_scalar_and_flat_accesses(tmp_path):
         f.write_text(text)
         found = mod.scan(str(f))
         assert len(found) == n, (name, found)
+    # second check: a fragment's registers touched while its read is in flight (no wait between the read and the use)
+    rd = "\t;;#ASMSTART\n\tds_read_b128 v[0:3], v4 offset:0\n\t;;#ASMEND\n"
+    wait = "\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n"
+    use = "\tv_mfma_f32_32x32x16_bf16 a[0:15], v[0:3], v[8:11], a[0:15]\n"
+    cases = {"waited": rd + wait + use, "copied_early": rd + "\tv_mov_b32_e32 v9, v2\n" + wait + use,
+             "clobbered": rd + "\tv_lshl_add_u64 v[2:3], v[20:21], 0, s[0:1]\n" + wait, "never_waited": rd + use}
+    for name, body in cases.items():
+        f = tmp_path / (name + ".s")
+        f.write_text("_Z1kv:\n" + body + "\ts_endpgm\n")
+        found = mod.scan_inflight(str(f))
+        assert (len(found) == 0) == (name == "waited"), (name, found)
