@@ -127,7 +127,9 @@ struct X16<N3DT_F16> {
 #ifndef X16_DEFAULT_TILING
 #define X16_DEFAULT_TILING 1  // 1: 8 waves x 32 samples, 2: 4 waves x 64 samples (N3DT_X16_TILING overrides at run time)
 #endif
-#define X16_NBUF 3
+#ifndef X16_NBUF
+#define X16_NBUF 3  // chunk buffers of the ring (4 measured no faster for the render kernel and the renderer blocks)
+#endif
 #define X16_CHUNK_BYTES (X16_CH * X16_PIECE)
 
 // Diagnostic build only (-DX16_STAMP): per-wave cycle sums of the three phases of a tile, written to the
