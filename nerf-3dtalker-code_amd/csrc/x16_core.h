@@ -119,7 +119,7 @@ struct X16<N3DT_F16> {
 #define X16_STAGGER 0
 #endif
 #ifndef X16_DEPTH
-#define X16_DEPTH 2
+#define X16_DEPTH 3  // fragments in flight per wave: 3 measured 0.6 % faster than 2 for the render kernel (same box), 4 spills it
 #endif
 #ifndef X16_DEFER
 #define X16_DEFER 0
@@ -309,7 +309,9 @@ struct WeightStream {
     // A RUN-TIME condition around read_frag / await_frag is not an option: the branch makes the fragment a phi and hipcc
     // copies the (not yet landed) registers ahead of the wait.
     __device__ __forceinline__ void settle() {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[X16_DEPTH - 1]));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]));
+#pragma unroll
+        for (int i = 1; i < X16_DEPTH; ++i) asm volatile("" : "+v"(a[i]));  // every slot stays reserved up to the wait
     }
 };
 
