@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: rendered frames/s of the head-render hot path on N MI355X GPUs.
 
-Workload (BASELINE.json configs[1], reference-faithful reading):
+Workload (BASELINE.json configs[1], reference-faithful reading R):
   one step = forward("test") of `--batch` synthetic heads per GPU: 64x64 rays x 64 samples/ray
   -> latent-conditioned MLP (fused HIP kernel) -> alpha compositing -> 2-D neural renderer ->
   512x512 RGB, plus the background image (the reference renders both every forward).
@@ -9,12 +9,18 @@ Inputs and weights are synthetic (seeded) and resident in HBM before the timed r
 Frames shard across ranks with no data-path collective (weak scaling: fixed frames per GPU).
 
 Contract: python bench.py --gpus N --steps K --warmup W  -> rank 0 prints ONE JSON line.
-Extra objects in that line:
+  `--gpus N` with N > 1 and no rendezvous environment: this process stays a plain launcher (it never imports
+  torch, never touches the GPU) and starts N ranks of itself (n3dt/launch.py); under `torch.distributed.run`
+  (WORLD_SIZE set) it is one of the ranks and WORLD_SIZE must equal --gpus.
+Extra objects in the line:
   roofline      the fused MLP kernel: algorithmic FLOP (2 702 592 per sample point)
                 / its average launch time (hipEvents recorded around that launch on its stream,
                 inside the timed region) against the dense bf16 MFMA peak.
   cpu_baseline  the CPU restatement (oracle/, an OpenMP port -- the reference's Python cannot
                 travel to the GPU box) timed on this host's cores on one frame of the workload.
+  extra         (N = 1 only) the other BASELINE configurations and modes, a few timed steps each:
+                cfg2-N (512^2 rays), cfg2-R in exact fp32, cfg2-R one head (latency), cfg3 training
+                step in bf16 and fp32, cfg4, cfg5.
 """
 import argparse
 import ctypes
@@ -30,66 +36,265 @@ sys.path.insert(0, REPO)
 FLOP_PER_POINT = 2702592          # latent-folded MLP query, SURVEY 8(d)
 FLOP_PER_POINT_EXECUTED = 2375 * 32768 // 32  # MFMA work actually issued per point: 2280 weight pieces + 95 bias MFMAs per 32 samples (RGB_layer_0 merged into RGB_layer_1, RGB_layer_2 per ray)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
+GEOMETRY = {"cfg2": (64, 64, 512), "cfg4": (32, 64, 256), "cfg5": (32, 96, 1024)}  # featmap_size, samples, image
 
 
-def bench_train(args, net, opt, d, dev, world, rank):
-    """BASELINE config 3: one reference-shaped train step = forward("train") -> 3 MSE terms -> backward -> Adam
-    (+ one flat-buffer RCCL all-reduce of the gradients when world > 1).  Exact-fp32 kernels."""
+def _load_launcher():
+    """n3dt/launch.py by path: importing the package would import torch, which the launcher parent must not need."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("n3dt_launch", os.path.join(REPO, "nerf-3dtalker-code_amd", "n3dt", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class Ctx:
+    """Rank / device / process group of this process."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with `python bench.py --gpus N` or "
+                             "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)" % (args.gpus, self.world))
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+        # one process per GPU.  N3DT_DIST_BACKEND=gloo is a rehearsal knob for boxes with fewer GPUs than ranks
+        # (ranks then share devices round-robin); the real runs use nccl = RCCL over xGMI.
+        self.backend = os.environ.get("N3DT_DIST_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        if self.backend == "nccl" and self.world > ndev:
+            raise SystemExit("bench.py: %d ranks but %d GPU(s) visible (N3DT_DIST_BACKEND=gloo rehearses on fewer)" % (self.world, ndev))
+        dev_index = local_rank if self.backend == "nccl" else local_rank % max(ndev, 1)
+        torch.cuda.set_device(dev_index)
+        self.dev = torch.device("cuda", dev_index)
+        if self.world > 1:
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+            assert dist.get_world_size() == self.world == args.gpus
+
+    def barrier(self):
+        import torch
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+
+    def max_over_ranks(self, seconds):
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def ranks_seen(self):
+        """Number of ranks the collective backend actually connects (an all-reduce of ones)."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return 1
+        t = torch.ones(1, dtype=torch.float32, device=self.dev if self.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(round(float(t.item())))
+
+    def close(self):
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.destroy_process_group()
+
+
+def build(ctx, config, precision, batch, rays="R", train_precision=None, first_frame=None):
     import torch
-    import torch.distributed as dist
-    from n3dt import parallel
-    from n3dt.train import fused_data_losses as data_losses, disk_mask
-    B = d["batch_xy"].shape[0]
-    net.precision = "fp32"
-    tp = "bf16" if args.precision == "bf16" else "fp32"
-    net.train_precision = tp
-    net.neural_render.train_precision = tp
-    optim = torch.optim.Adam(net.parameters(), lr=1e-4)
-    gt = torch.full((B, 3, opt.pred_img_size, opt.pred_img_size), 0.5, device=dev)
-    mask = disk_mask(B, opt.pred_img_size).to(dev)
-    if world > 1:
-        parallel.broadcast_parameters(net)
+    from n3dt import HeadNeRFNet, BaseOptions, synthetic as syn
+    fs, ns, pred = GEOMETRY[config]
+    opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": pred, "num_sample_coarse": ns})
+    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
+    net = HeadNeRFNet(opt, include_vd=False, hier_sampling=False, precision=precision,
+                      train_precision=train_precision or "fp32").to(ctx.dev)
+    net.load_state_dict(sd, strict=True)
+    n_side = 512 if rays == "N" else None
+    # every rank renders its own frames: frame indices rank*B .. rank*B+B-1
+    inp = syn.frame_inputs(opt, batch, n_side=n_side, first_frame=ctx.rank * batch if first_frame is None else first_frame)
+    d = {k: (v.to(ctx.dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    return opt, sd, net, d
+
+
+def run_render(ctx, config, precision, batch, rays, steps, warmup):
+    """forward("test") of `batch` heads per rank per step (reading N: the feature stage on 512^2 rays)."""
+    import numpy as np
+    import torch
+    from n3dt import _lib
+    opt, sd, net, d = build(ctx, config, precision, batch, rays)
+    fs, ns, pred = GEOMETRY[config]
 
     def step():
-        pred = net("train", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"],
-                   d["batch_Rmats"], d["batch_Tvecs"], d["batch_inv_inmats"])
-        t = data_losses(pred["coarse_dict"], gt, mask)
+        if rays == "R":
+            return net("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"],
+                       d["batch_Rmats"], d["batch_Tvecs"], d["batch_inv_inmats"])
+        return net.render_features(d["batch_xy"], d["audiostyle"], d["shape_code"], d["appea_code"], d["batch_Rmats"],
+                                   d["batch_Tvecs"], d["batch_inv_inmats"], want_merge=False)
+
+    L = _lib.lib()
+    with torch.no_grad():
+        for _ in range(warmup):
+            step()
+        ctx.barrier()
+        L.n3dt_prof_enable(steps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ctx.barrier()
+        elapsed = time.perf_counter() - t0
+    ms = (ctypes.c_float * steps)()
+    n_rec = ctypes.c_int(0)
+    L.n3dt_prof_collect(ms, steps, ctypes.byref(n_rec))
+    L.n3dt_prof_enable(0)
+    kern_ms = float(np.mean([ms[i] for i in range(n_rec.value)])) if n_rec.value else float("nan")
+    elapsed = ctx.max_over_ranks(elapsed)
+    n_rays = d["batch_xy"].shape[-1]
+    points = batch * n_rays * ns
+    achieved = points * FLOP_PER_POINT / (kern_ms * 1e-3) / 1e12
+    return {
+        "opt": opt, "sd": sd, "elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps,
+        "frames_per_s": ctx.world * batch * steps / elapsed, "kern_ms": kern_ms, "points": points, "n_rays": n_rays,
+        "achieved": achieved, "frac": achieved / PEAK_TFLOPS[precision],
+        "workload": ("%s-R: %d heads/GPU/step, %dx%d rays x %d samples -> fused MLP+composite -> neural renderer "
+                     "-> %dx%d RGB (+ background image)" % (config, batch, fs, fs, ns, pred, pred)) if rays == "R" else
+                    ("%s-N: %d heads/GPU/step, 512x512 rays x %d samples, feature stage only" % (config, batch, ns)),
+    }
+
+
+def run_train(ctx, config, train_precision, batch, steps, warmup, audio2style_bucket=True):
+    """BASELINE config 3: one reference-shaped train step = forward("train") -> 3 MSE terms -> backward -> Adam x 2
+    (talker_trainer.py:1002-1067), plus -- when world > 1 -- ONE flat-buffer all-reduce of the gradients of
+    HeadNeRFNet and of a 21.5 M-parameter stand-in for the co-trained Audio2style module (talker_trainer.py:428-473,665)."""
+    import torch
+    from n3dt import parallel
+    from n3dt.train import fused_data_losses as data_losses, disk_mask
+    opt, sd, net, d = build(ctx, config, "fp32", batch, "R", train_precision=train_precision)
+    fs, ns, pred = GEOMETRY[config]
+    optim = torch.optim.Adam(net.parameters(), lr=1e-4)
+    bucket = optim_a2s = None
+    if audio2style_bucket and ctx.world > 1:
+        bucket = parallel.FlatBucket().to(ctx.dev)
+        optim_a2s = torch.optim.Adam(bucket.parameters(), lr=1e-7, betas=(0.5, 0.999))
+    gt = torch.full((batch, 3, pred, pred), 0.5, device=ctx.dev)
+    mask = disk_mask(batch, pred).to(ctx.dev)
+    if ctx.world > 1:
+        parallel.broadcast_parameters(net)
+    reduce_params = list(net.parameters()) + (list(bucket.parameters()) if bucket is not None else [])
+
+    def step():
+        pred_ = net("train", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"],
+                    d["batch_Rmats"], d["batch_Tvecs"], d["batch_inv_inmats"])
+        t = data_losses(pred_["coarse_dict"], gt, mask)
         loss = t["bg_loss"] + t["head_loss"] + t["nonhead_loss"]
         optim.zero_grad()
         loss.backward()
-        parallel.allreduce_gradients(net.parameters(), world)
+        if bucket is not None:
+            bucket.fill_grad(1e-3)  # the LSTM's backward is outside the path; its gradient bytes are not
+        parallel.allreduce_gradients(reduce_params, ctx.world)
         optim.step()
+        if optim_a2s is not None:
+            optim_a2s.step()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    ctx.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu") if world > 1 else \
-        torch.tensor([elapsed], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.destroy_process_group()
-    elapsed = float(t.item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "trained frames/sec @%d^2 x %d samples/ray (fwd+bwd+Adam)" % (opt.pred_img_size, opt.num_sample_coarse),
-            "value": world * B * args.steps / elapsed,
-            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": tp, "data": "synthetic",
-            "config": {"workload": "%s: %d heads/GPU/step, %dx%d rays x %d samples -> %dx%d, 3 MSE terms, Adam" % (
-                "cfg3" if args.config == "cfg2" else args.config + "-train", B, opt.featmap_size, opt.featmap_size,
-                opt.num_sample_coarse, opt.pred_img_size, opt.pred_img_size),
-                       "parallelism": "frames sharded over %d rank(s), one flat gradient all-reduce per step" % world},
-        }), flush=True)
+    ctx.barrier()
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    return {
+        "elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "frames_per_s": ctx.world * batch * steps / elapsed,
+        "allreduce_bytes_per_step": 4 * sum(p.numel() for p in reduce_params) if ctx.world > 1 else 0,
+        "workload": "%s: %d heads/GPU/step, %dx%d rays x %d samples -> %dx%d, 3 MSE terms, Adam" % (
+            "cfg3" if config == "cfg2" else config + "-train", batch, fs, fs, ns, pred, pred),
+    }
+
+
+def cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return model, os.cpu_count() or 1, avail
+
+
+def cpu_baseline(opt, sd, rays):
+    """The C restatement (oracle/) on this host: one cfg2-R frame, at the box's CPU share and at 8 threads."""
+    from n3dt import synthetic as syn
+    from oracle import oracle as orc
+    model, nproc, avail = cpu_info()
+    # the GPU box exposes every host core but grants a 16-CPU share per GPU: more threads only thrash
+    cores = max(1, min(avail, int(os.environ.get("N3DT_CPU_THREADS", "16"))))
+    one = syn.frame_inputs(opt, 1)
+    skip = rays == "N"
+
+    def timed(threads, reps):
+        orc.set_num_threads(threads)
+        orc.forward(sd, opt, one, skip_neural_render=skip)  # warm (page-in, thread pool)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            orc.forward(sd, opt, one, skip_neural_render=skip)
+        return (time.perf_counter() - t1) / reps
+
+    s_main = timed(cores, 2)
+    s_8 = timed(min(8, avail), 1) if cores != 8 else s_main
+    return {
+        "value": 1.0 / s_main, "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": "2 x 1 frame of the cfg2-R workload (64x64 rays x 64 samples -> 512^2), fp32 OpenMP C restatement (oracle/)",
+        "cpu_model": model, "nproc": nproc, "cpus_available": avail,
+        "value_8_threads": 1.0 / s_8, "seconds_per_frame": s_main, "seconds_per_frame_8_threads": s_8,
+    }
+
+
+def extras(ctx):
+    """The other configurations and modes of BASELINE.json / DESIGN section 5, each a few timed steps (N = 1 only)."""
+    import torch
+    out = {}
+
+    def rec(name, note, fn, steps, warmup):
+        try:
+            r = fn(steps, warmup)
+            e = {"workload": r["workload"] + " [%s]" % note, "ms_per_step": r["ms_per_step"], "frames_per_s": r["frames_per_s"],
+                 "steps": steps, "warmup": warmup}
+            if "frac" in r:
+                e["fused_mlp_kernel_ms"] = r["kern_ms"]
+                e["roofline_frac"] = r["frac"]
+            out[name] = e
+        except Exception as exc:  # a failed extra must not take the headline line with it
+            out[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    rec("cfg2-N_bf16_b1", "bf16", lambda k, w: run_render(ctx, "cfg2", "bf16", 1, "N", k, w), 4, 2)
+    rec("cfg2-R_fp32_b4", "fp32 parity mode", lambda k, w: run_render(ctx, "cfg2", "fp32", 4, "R", k, w), 4, 2)
+    rec("cfg2-R_bf16_b1", "bf16, one head per step (latency)", lambda k, w: run_render(ctx, "cfg2", "bf16", 1, "R", k, w), 20, 5)
+    rec("cfg3_train_bf16_b2", "fused bf16 training path", lambda k, w: run_train(ctx, "cfg2", "bf16", 2, k, w), 5, 2)
+    rec("cfg3_train_fp32_b2", "exact fp32 training path", lambda k, w: run_train(ctx, "cfg2", "fp32", 2, k, w), 4, 2)
+    rec("cfg4_bf16_b4", "bf16", lambda k, w: run_render(ctx, "cfg4", "bf16", 4, "R", k, w), 20, 5)
+    rec("cfg4_train_bf16_b2", "fused bf16 training path", lambda k, w: run_train(ctx, "cfg4", "bf16", 2, k, w), 5, 2)
+    rec("cfg5_bf16_b4", "bf16", lambda k, w: run_render(ctx, "cfg5", "bf16", 4, "R", k, w), 10, 3)
+    return out
 
 
 def main():
@@ -102,150 +307,97 @@ def main():
     ap.add_argument("--rays", default="R", choices=["R", "N"],
                     help="R: rays = featmap_size^2 (reference-faithful); N: 512^2 rays, feature stage only")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
-                    help="render: forward-only (BASELINE config 2, the headline); train: fwd+loss+bwd+Adam (config 3, fp32)")
+                    help="render: forward-only (BASELINE config 2, the headline); train: fwd+loss+bwd+Adam (config 3)")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
                     help="BASELINE.json geometry: cfg2 (headline: 64x64 rays x 64 samples -> 512^2; cfg3 with --mode train), "
                          "cfg4 (32x32 rays x 64 samples -> 256^2, 4 heads per GPU), cfg5 (HR: 32x32 rays x 96 samples -> 1024^2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `extra` sub-records (N = 1 render runs carry them by default)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+
+    # ---- launcher: no torch, no GPU in this process ---------------------------------------------------------------
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        rc = _load_launcher().spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        sys.exit(rc)
+
+    default_workload = args.config == "cfg2" and args.mode == "render" and args.rays == "R" and args.precision == "bf16"
     if args.config != "cfg2":
         args.no_cpu_baseline = True  # the reported CPU baseline is the headline workload's
         if args.batch == 16:
             args.batch = 4
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    from n3dt import HeadNeRFNet, BaseOptions, synthetic as syn, _lib
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    # one process per GPU.  N3DT_DIST_BACKEND=gloo is a rehearsal knob for boxes with fewer GPUs than ranks
-    # (ranks then share devices round-robin); the real runs use nccl = RCCL over xGMI.
-    backend = os.environ.get("N3DT_DIST_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    fs, ns, pred = {"cfg2": (64, 64, 512), "cfg4": (32, 64, 256), "cfg5": (32, 96, 1024)}[args.config]
-    opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": pred, "num_sample_coarse": ns})
-    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
-    net = HeadNeRFNet(opt, include_vd=False, hier_sampling=False, precision=args.precision).to(dev)
-    net.load_state_dict(sd, strict=True)
-    B = args.batch if args.mode == "render" else min(args.batch, 2)
-    n_side = 512 if args.rays == "N" else None
-    # every rank renders its own frames: frame indices rank*B .. rank*B+B-1
-    inp = syn.frame_inputs(opt, B, n_side=n_side, first_frame=rank * B)
-    d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
-    n_rays = d["batch_xy"].shape[-1]
-    points_per_step = B * n_rays * ns
+    ctx = Ctx(args)
+    seen = ctx.ranks_seen()
+    assert seen == args.gpus, "the collective backend connects %d ranks, --gpus says %d" % (seen, args.gpus)
 
     if args.mode == "train":
-        return bench_train(args, net, opt, d, dev, world, rank)
+        tp = "bf16" if args.precision == "bf16" else "fp32"
+        B = min(args.batch, 2)
+        r = run_train(ctx, args.config, tp, B, args.steps, args.warmup)
+        if ctx.rank == 0:
+            fs, ns, pred = GEOMETRY[args.config]
+            print(json.dumps({
+                "metric": "trained frames/sec @%d^2 x %d samples/ray (fwd+bwd+Adam)" % (pred, ns),
+                "value": r["frames_per_s"], "unit": "frames/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": tp, "data": "synthetic",
+                "config": {"workload": r["workload"],
+                           "parallelism": "frames sharded over %d rank(s), one flat gradient all-reduce per step "
+                                          "(HeadNeRFNet + a 21.5 M-parameter Audio2style stand-in bucket)" % ctx.world,
+                           "allreduce_bytes_per_step": r["allreduce_bytes_per_step"], "ranks_seen_by_backend": seen},
+            }), flush=True)
+        ctx.close()
+        return
 
-    def step():
-        if args.rays == "R":
-            return net("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"],
-                       d["batch_Rmats"], d["batch_Tvecs"], d["batch_inv_inmats"])
-        return net.render_features(d["batch_xy"], d["audiostyle"], d["shape_code"], d["appea_code"], d["batch_Rmats"],
-                                   d["batch_Tvecs"], d["batch_inv_inmats"], want_merge=False)
-
-    L = _lib.lib()
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        L.n3dt_prof_enable(args.steps)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-    ms = (ctypes.c_float * args.steps)()
-    n_rec = ctypes.c_int(0)
-    L.n3dt_prof_collect(ms, args.steps, ctypes.byref(n_rec))
-    L.n3dt_prof_enable(0)
-    kern_ms = float(np.mean([ms[i] for i in range(n_rec.value)])) if n_rec.value else float("nan")
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-    if rank == 0:
-        frames = world * B * args.steps
-        achieved = points_per_step * FLOP_PER_POINT / (kern_ms * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[args.precision]
-        traffic = None
+    r = run_render(ctx, args.config, args.precision, args.batch, args.rays, args.steps, args.warmup)
+    res = None
+    if ctx.rank == 0:
+        fs, ns, pred = GEOMETRY[args.config]
+        traffic, traffic_src = None, None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("%s_%s_b%d" % (args.rays, args.precision, B))
+                traffic = json.load(f).get("%s_%s_b%d" % (args.rays, args.precision, args.batch))
+            if traffic is not None:
+                traffic_src = "profiles/traffic.json (rocprofv3 PMC passes of this command; not re-measured in this run)"
         res = {
             "metric": "rendered frames/sec @%d^2 x %d samples/ray" % (pred, ns),
-            "value": frames / elapsed,
+            "value": r["frames_per_s"],
             "unit": "frames/s",
-            "n_gpus": world,
+            "n_gpus": ctx.world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": r["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
             "config": {
-                "workload": ("%s-R: %d heads/GPU/step, %dx%d rays x %d samples -> fused MLP+composite -> neural renderer "
-                             "-> %dx%d RGB (+ background image)" % (args.config, B, fs, fs, ns, pred, pred)) if args.rays == "R" else
-                            ("%s-N: %d heads/GPU/step, 512x512 rays x %d samples, feature stage only" % (args.config, B, ns)),
-                "frames_per_gpu_per_step": B, "rays_per_frame": n_rays, "samples_per_ray": ns,
-                "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
+                "workload": r["workload"],
+                "frames_per_gpu_per_step": args.batch, "rays_per_frame": r["n_rays"], "samples_per_ray": ns,
+                "parallelism": "frames sharded over %d rank(s), no data-path collective" % ctx.world,
+                "ranks_seen_by_backend": seen,
             },
             "roofline": {
                 "kernel": "nerf_fwd_x16_kernel" if args.precision != "fp32" else "nerf_fwd_f32_kernel",
-                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": traffic,
-                "avg_launch_ms": kern_ms, "points_per_launch": points_per_step,
+                "bound": "mfma", "achieved": r["achieved"], "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s", "frac": r["frac"],
+                "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": r["kern_ms"], "points_per_launch": r["points"],
                 "flop_per_point_algorithmic": FLOP_PER_POINT,
-                "executed_tflops": points_per_step * FLOP_PER_POINT_EXECUTED / (kern_ms * 1e-3) / 1e12,
+                "executed_tflops": r["points"] * FLOP_PER_POINT_EXECUTED / (r["kern_ms"] * 1e-3) / 1e12,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import oracle as orc
-            # the GPU box exposes every host core but grants a 16-CPU share per GPU: more threads only thrash
-            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            cores = max(1, min(avail, int(os.environ.get("N3DT_CPU_THREADS", "16"))))
-            orc.set_num_threads(cores)
-            one = syn.frame_inputs(opt, 1)
-            orc.forward(sd, opt, one, skip_neural_render=(args.rays == "N"))  # warm (page-in, thread pool)
-            t1 = time.perf_counter()
-            reps = 2
-            for _ in range(reps):
-                orc.forward(sd, opt, one, skip_neural_render=(args.rays == "N"))
-            cpu_s = (time.perf_counter() - t1) / reps
-            res["cpu_baseline"] = {
-                "value": 1.0 / cpu_s, "unit": "frames/s", "cores": cores, "kind": "port",
-                "sample": "%d x 1 frame of the cfg2-R workload (64x64 rays x 64 samples -> 512^2), fp32 OpenMP C restatement" % reps,
-            }
+    if ctx.world == 1:
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(r["opt"], r["sd"], args.rays)
+        if default_workload and not args.no_extras:
+            res["extra"] = extras(ctx)
+    if ctx.rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == "__main__":

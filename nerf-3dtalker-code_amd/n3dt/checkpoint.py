@@ -19,6 +19,9 @@ def load_ckpt(model, state_dict):
             own[k].copy_(v)
         else:
             skipped.append(k)
+    for m in model.modules():  # packed weight copies follow version counters; be explicit anyway
+        if hasattr(m, "invalidate_packed"):
+            m.invalidate_packed()
     return skipped
 
 

@@ -323,6 +323,16 @@ class HeadNeRFNet(nn.Module):
         self._build_tool_funcs()
         self.neural_render.train_precision = train_precision
         self._pack_cache = {}
+        # a (strict or not) load_state_dict replaces every weight: drop the packed copies
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_packed())
+
+    def invalidate_packed(self):
+        """Forget the packed (MFMA-ordered, 16-bit) copies of the MLP weights.  They are rebuilt on the next call.
+        The cache follows the parameters' version counters, which optimizers, `copy_` under no_grad and
+        `load_state_dict` all move; writes through `.data` (the reference's own `load_ckpt` does
+        `model.state_dict()[k].data.copy_(v)`, talker_trainer.py:557-567) do NOT move them -- call this after such a
+        write, or use n3dt.checkpoint.load_ckpt, which does."""
+        self._pack_cache.clear()
 
     def _build_info(self, opt):
         self.num_sample_coarse = opt.num_sample_coarse

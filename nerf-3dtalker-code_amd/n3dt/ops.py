@@ -29,13 +29,16 @@ def _f32c(t):
 
 
 class _Workspace:
-    """Grow-only per-device scratch buffers, keyed by role (stream-ordered reuse)."""
+    """Grow-only scratch buffers keyed by (role, device, stream): reuse is ordered by the stream the kernels are
+    enqueued on, so two streams (or two modules driven from two streams) never share scratch.  A buffer that is
+    outgrown goes back to the caching allocator, which is stream-aware for the stream it was allocated on -- the
+    one that used it."""
 
     def __init__(self):
         self.buf = {}
 
     def get(self, key, nbytes, device):
-        k = (key, device.index)
+        k = (key, device.index, torch.cuda.current_stream(device).cuda_stream)
         b = self.buf.get(k)
         if b is None or b.numel() < nbytes:
             b = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

@@ -1,0 +1,68 @@
+"""Rank body for tests/test_parallel_cpu.py::test_launcher_* : started N times by n3dt.launch.spawn_ranks (the same
+function `bench.py --gpus N` uses), gloo backend, CPU only.  Drives n3dt.parallel over the parameter list of a real
+n3dt.HeadNeRFNet(hier_sampling=True) built on the CPU (no forward: the HIP path has no CPU fallback) -- including
+parameters without a gradient and the Blur buffers that broadcast_parameters carries."""
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "nerf-3dtalker-code_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from n3dt import HeadNeRFNet, BaseOptions, parallel  # noqa: E402
+
+
+def main():
+    out_dir = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["LOCAL_RANK"]) == rank
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert dist.get_world_size() == world
+    opt = BaseOptions({"featmap_size": 8, "featmap_nc": 256, "pred_img_size": 32, "num_sample_coarse": 8})
+    torch.manual_seed(100 + rank)  # every rank starts from DIFFERENT weights
+    net = HeadNeRFNet(opt, include_vd=False, hier_sampling=True)
+    net._pack_cache["stale"] = ("x", None)  # stands for a packed copy made before the broadcast
+    with torch.no_grad():
+        net.neural_render.rgb_upsample[1].f.add_(float(rank))  # a buffer that differs per rank
+    before = [p._version for p in net.parameters()]
+    parallel.broadcast_parameters(net)
+    assert not net._pack_cache, "broadcast_parameters must drop the packed weight copies"
+    assert all(p._version > v for p, v in zip(net.parameters(), before)), \
+        "broadcast must move the version counters (the packed-weight cache follows them)"
+    # gradients: rank-dependent on the coarse network and the renderer, NONE on the fine network (as after a
+    # backward that never reached it) -- the flat buffer must keep the same layout on every rank
+    bucket = parallel.FlatBucket(numel=1000)
+    gen = torch.Generator().manual_seed(7)
+    base = {}
+    for name, p in net.named_parameters():
+        g = torch.randn(p.shape, generator=gen)
+        base[name] = g
+        if not name.startswith("fine_fg_CD_predictor."):
+            p.grad = g * float(rank + 1)
+    bucket.fill_grad(float(rank + 1))
+    params = list(net.parameters()) + list(bucket.parameters())
+    parallel.allreduce_gradients(params, world)
+    mean = sum(range(1, world + 1)) / world
+    worst = 0.0
+    for name, p in net.named_parameters():
+        want = torch.zeros_like(p) if name.startswith("fine_fg_CD_predictor.") else base[name] * mean
+        worst = max(worst, float((p.grad - want).abs().max()))
+    worst = max(worst, float((bucket.flat.grad - mean).abs().max()))
+    csum = float(sum(p.detach().double().sum() for p in net.parameters()) + sum(b.double().sum() for b in net.buffers()))
+    # bench.py's timing protocol: barrier, MAX over ranks
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.barrier()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
+        json.dump({"rank": rank, "world": world, "worst_grad_err": worst, "weights_checksum": csum, "max_t": float(t),
+                   "n_reduced": sum(p.numel() for p in params)}, f)
+    dist.destroy_process_group()
+    if len(sys.argv) > 2 and sys.argv[2] == "fail" and rank == 1:
+        sys.exit(7)
+
+
+if __name__ == "__main__":
+    main()
