@@ -34,7 +34,7 @@ struct X16SaveStage {
     typename X16<PREC>::frag I0, I1;
 };
 
-template <int PREC, int NB, int WAVES, bool LATE, int KS, int KPE, int NT, int MODE, bool SAVE = false>
+template <int PREC, int NB, int WAVES, int KS, int KPE, int NT, int MODE, bool SAVE = false>
 __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const float* __restrict__ bias,
                                           const typename X16<PREC>::frag (&pe_reg)[NB][4], const unsigned char* pe_lds,
                                           const typename X16<PREC>::frag (&hin)[NB][24], typename X16<PREC>::frag (&hout)[NB][24],
@@ -46,27 +46,22 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
     float red[NB][32];
     const frag ones = X16<PREC>::ones_frag();
     float bias_cur = bias[c];
-    // Two accumulator sets: tile ot accumulates into acc[ot & 1] while the epilogue of tile ot-1 (pack to 16 bit,
-    // ReLU) is placed between this tile's MFMAs -- VALU work issues under the matrix pipe instead of after it.
-    // X16_DEFER=1 measured perf-neutral (the wave is not VALU-bound in its epilogue) and costs 12 VGPRs: off by default
     constexpr bool PACKS = (MODE == MODE_HIDDEN || MODE == MODE_LINEAR);
-    constexpr bool DEFER = PACKS && X16_DEFER;
-    f32x16 acc[2][NB];
+    f32x16 acc[1][NB];
     auto finish_half = [&](const int t, const int half) {  // registers 8*half .. 8*half+7 of tile t -> k-step 2t+half
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             float v[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = acc[DEFER ? (t & 1) : 0][nb][8 * half + r];
+            for (int r = 0; r < 8; ++r) v[r] = acc[0][nb][8 * half + r];
             frag f = X16<PREC>::pack(v);
             if (MODE == MODE_HIDDEN) f = X16<PREC>::relu(f, relu_lo);
             hout[nb][2 * t + half] = f;
         }
     };
-    constexpr int E0 = KS >= 8 ? 2 : 1, E1 = KS >= 8 ? 6 : (KS - 1);
     static_for<0, NT>([&](auto ot_c) {
         constexpr int ot = decltype(ot_c)::value;
-        constexpr int cur = DEFER ? (ot & 1) : 0;
+        constexpr int cur = 0;
         X16_T(const unsigned long long s0 = x16_now();)
         {
             // acc = bias, broadcast over the samples, by ONE extra MFMA (hi/lo split keeps ~16 mantissa bits):
@@ -83,7 +78,7 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
         X16_T(const unsigned long long s1 = x16_now(); const unsigned long long rv0 = ws.t_rv;)
         static_for<0, KS>([&](auto ks_c) {
             constexpr int ks = decltype(ks_c)::value;
-            const frag a_cur = ws.template next<LATE, MODE == MODE_COMPOSITE, NT * KS, ot * KS + ks>();
+            const frag a_cur = ws.template next<MODE == MODE_COMPOSITE, NT * KS, ot * KS + ks>();
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 frag b;
@@ -95,11 +90,9 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
                 }
                 acc[cur][nb] = X16<PREC>::mfma(a_cur, b, acc[cur][nb]);
             }
-            if (DEFER && ot > 0 && ks == E0) finish_half(ot - 1, 0);
-            if (DEFER && ot > 0 && ks == E1) finish_half(ot - 1, 1);
         });
         X16_T(const unsigned long long s2 = x16_now();)
-        if (PACKS && (!DEFER || ot == NT - 1)) {
+        if (PACKS) {
             finish_half(ot, 0);
             finish_half(ot, 1);
         }
@@ -153,7 +146,7 @@ struct X16TrainSave {
     float* geo;
 };
 
-template <int PREC, int NB, int WAVES, bool LATE, bool SAVE = false>
+template <int PREC, int NB, int WAVES, bool SAVE = false>
 __device__ __forceinline__ void nerf_fwd_x16_body(
     const N3dtGeom& g, const unsigned char* __restrict__ packed, const float* __restrict__ fold, const float* __restrict__ xy,
     const float* __restrict__ R, const float* __restrict__ T, const float* __restrict__ Kinv, const float* __restrict__ t_rand,
@@ -239,19 +232,19 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
     frag ha[NB][24], hb[NB][24];
     float aux[NB];
     // FeaExt_module_0 (reference: NetWorks/models.py:69-71)
-    x16_stage<PREC, NB, WAVES, LATE, 4, 4, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(0), pe, nullptr, ha, ha, aux, po, live, lane, sv_hidden(0));
+    x16_stage<PREC, NB, WAVES, 4, 4, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(0), pe, nullptr, ha, ha, aux, po, live, lane, sv_hidden(0));
     // FeaExt_module_1..7 with the skip concat after layer 4 (models.py:72-76).  Fully unrolled on purpose: rolling the
     // identical 384->384 layers into a loop (tried: one-layer body + register copy, two-layer ping-pong body) makes the
     // register allocator spill 120-270 VGPRs across the back edge and runs 1.7x slower.
-    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(1), pe, nullptr, ha, hb, aux, po, live, lane, sv_hidden(1));
-    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(2), pe, nullptr, hb, ha, aux, po, live, lane, sv_hidden(2));
-    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(3), pe, nullptr, ha, hb, aux, po, live, lane, sv_hidden(3));
-    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(4), pe, nullptr, hb, ha, aux, po, live, lane, sv_hidden(4));
-    x16_stage<PREC, NB, WAVES, LATE, 28, 4, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(5), pe, pe_lds, ha, hb, aux, po, live, lane, sv_hidden(5));
-    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(6), pe, nullptr, hb, ha, aux, po, live, lane, sv_hidden(6));
-    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(7), pe, nullptr, ha, hb, aux, po, live, lane, sv_hidden(7));
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(1), pe, nullptr, ha, hb, aux, po, live, lane, sv_hidden(1));
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(2), pe, nullptr, hb, ha, aux, po, live, lane, sv_hidden(2));
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(3), pe, nullptr, ha, hb, aux, po, live, lane, sv_hidden(3));
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(4), pe, nullptr, hb, ha, aux, po, live, lane, sv_hidden(4));
+    x16_stage<PREC, NB, WAVES, 28, 4, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(5), pe, pe_lds, ha, hb, aux, po, live, lane, sv_hidden(5));
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(6), pe, nullptr, hb, ha, aux, po, live, lane, sv_hidden(6));
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(7), pe, nullptr, ha, hb, aux, po, live, lane, sv_hidden(7));
     // density head on h7 (models.py:78,84); the bias rides in the accumulator
-    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 1, MODE_DENSITY, false>(ws, fb + n3dt_bias_offset(8), pe, nullptr, hb, ha, aux, po, live, lane);
+    x16_stage<PREC, NB, WAVES, 24, 0, 1, MODE_DENSITY, false>(ws, fb + n3dt_bias_offset(8), pe, nullptr, hb, ha, aux, po, live, lane);
     // alpha, in-block transmittance and weights (reference: NetWorks/utils.py:273-289)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -288,7 +281,7 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
     // RGB_layer_0 -> RGB_layer_1 as ONE merged 192 x 384 layer on h7 (no activation sits between them, models.py:79-81;
     // merged matrix and bias built by pack / fold), relu, weighted by the sample weights and reduced over the samples
     if constexpr (SAVE) svs.tile0 = live[0] ? tsv.gS + (size_t)blk[0] * 12 * X16_PIECE + lane * 16 : nullptr;
-    x16_stage<PREC, NB, WAVES, LATE, 24, 0, 6, MODE_COMPOSITE, SAVE>(ws, fb + n3dt_bias_offset(10), pe, nullptr, hb, ha, aux, po, live, lane,
+    x16_stage<PREC, NB, WAVES, 24, 0, 6, MODE_COMPOSITE, SAVE>(ws, fb + n3dt_bias_offset(10), pe, nullptr, hb, ha, aux, po, live, lane,
                                                                      SAVE ? &svs : nullptr);
 #ifdef X16_STAMP
     if (wlocal && lane == 0 && live[0]) {
@@ -308,11 +301,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerf_fwd_x16_kernel(
     float* __restrict__ part, float* __restrict__ wlocal, int bpr, long total_blocks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // the two halves of the workgroup run the same stream half a chunk apart (see WeightStream)
-    if (X16_STAGGER && wave >= WAVES / 2)
-        nerf_fwd_x16_body<PREC, NB, WAVES, true>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, bpr, total_blocks, lds, wave);
-    else
-        nerf_fwd_x16_body<PREC, NB, WAVES, false>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, bpr, total_blocks, lds, wave);
+    nerf_fwd_x16_body<PREC, NB, WAVES>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, bpr, total_blocks, lds, wave);
 }
 
 // Training forward (bf16, one block per wave): the same body, leaving the activations behind (X16TrainSave)
@@ -323,7 +312,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerf_fwd_x16_train_kernel(
     float* __restrict__ part, float* __restrict__ wlocal, int bpr, long total_blocks, X16TrainSave tsv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    nerf_fwd_x16_body<N3DT_BF16, 1, WAVES, false, true>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, bpr, total_blocks, lds, wave,
+    nerf_fwd_x16_body<N3DT_BF16, 1, WAVES, true>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, bpr, total_blocks, lds, wave,
                                                         tsv);
 }
 

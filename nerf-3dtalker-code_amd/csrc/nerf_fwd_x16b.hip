@@ -68,7 +68,7 @@ __device__ __forceinline__ void x16b_stage(WeightStream<PREC, WAVES>& ws, const 
         }
         static_for<0, KS>([&](auto ks_c) {
             constexpr int ks = decltype(ks_c)::value;
-            const frag a_cur = ws.template next<false, MODE == B_COMPOSITE, NT * KS, t * KS + ks>();
+            const frag a_cur = ws.template next<MODE == B_COMPOSITE, NT * KS, t * KS + ks>();
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 frag b;

@@ -113,16 +113,10 @@ struct X16<N3DT_F16> {
 //   * rendezvous n (one workgroup barrier) is met X16_DEPTH pieces BEFORE the end of chunk n: it makes chunk
 //     n+1 visible (issued at rendezvous n-1) and issues chunk n+2 into the buffer of chunk n-1, which every
 //     wave has left by then -- so fragment prefetches run across chunk boundaries without a bubble;
-//   * X16_STAGGER: waves WAVES/2.. (the SIMD partners of waves 0..) meet half a chunk earlier in THEIR stream,
-//     i.e. they run half a chunk behind, so one wave's accumulator epilogue overlaps its partner's MFMAs.
-#ifndef X16_STAGGER
-#define X16_STAGGER 0
-#endif
+//   (a half-chunk stagger of the SIMD partner waves and an epilogue deferred onto a second accumulator set were
+//   measured perf-neutral or worse in round 1 -- DESIGN 3.1 log items 3, 8, 11 -- and are gone from the source.)
 #ifndef X16_DEPTH
 #define X16_DEPTH 3  // fragments in flight per wave: 3 measured 0.6 % faster than 2 for the render kernel (same box), 4 spills it
-#endif
-#ifndef X16_DEFER
-#define X16_DEFER 0
 #endif
 #ifndef X16_DEFAULT_TILING
 #define X16_DEFAULT_TILING 1  // 1: 8 waves x 32 samples, 2: 4 waves x 64 samples (N3DT_X16_TILING overrides at run time)
@@ -273,9 +267,9 @@ struct WeightStream {
     }
     // Fragment of stage-local piece P (stages are whole chunks, so P % X16_CH and P % X16_DEPTH equal their
     // stream-global values).  LAST/NP: the final stage must not prefetch past the end of the stream.
-    template <bool LATE, bool LAST, int NP, int P>
+    template <bool LAST, int NP, int P>
     __device__ __forceinline__ frag next() {
-        constexpr int rv = (LATE ? X16_CH / 2 : X16_CH) - X16_DEPTH;
+        constexpr int rv = X16_CH - X16_DEPTH;
         if (P % X16_CH == rv) {
             X16_T(const unsigned long long r0 = x16_now();)
             rendezvous();

@@ -146,6 +146,19 @@ def make_state_dict(opt, seed=0, include_gaze=False, eye_gaze_dim=2, audio_dim=6
     return sd
 
 
+def contrast_state_dict(opt, seed=0, density_gain=400.0, density_bias=-60.0, feat_gain=40.0):
+    """Seeded weights that stress the 16-bit modes (fixture `contrast`): the density head is scaled (and biased negative)
+    so that alpha saturates on part of the rays and vanishes on others -- sharp weights, front-most samples carrying the
+    whole ray -- and RGB_layer_2 is scaled so that features are O(10)."""
+    sd = make_state_dict(opt, seed=seed, bg_noise=0.1)
+    p = "fg_CD_predictor."
+    sd[p + "density_module.weight"] = sd[p + "density_module.weight"] * density_gain
+    sd[p + "density_module.bias"] = sd[p + "density_module.bias"] + density_bias
+    sd[p + "RGB_layer_2.weight"] = sd[p + "RGB_layer_2.weight"] * feat_gain
+    sd[p + "RGB_layer_2.bias"] = sd[p + "RGB_layer_2.bias"] * feat_gain
+    return sd
+
+
 def state_dict_checksum(sd):
     """Cheap drift detector stored next to every fixture."""
     tot, asum = 0.0, 0.0

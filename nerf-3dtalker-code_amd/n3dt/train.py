@@ -38,11 +38,21 @@ class _FusedDataLoss(torch.autograd.Function):
         import ctypes
         from . import ops
         from ._lib import lib, check
-        B, _, P, _ = merge_img.shape
+        B, _, P, Q = merge_img.shape
+        # the kernel's contract (csrc/loss_tail.hip): ONE background image [1,3,P,P] (HeadNeRFNet.py:109 renders it at
+        # batch 1), images [B,3,P,P], mask [B,1,P,P], all on the device of merge_img
+        if tuple(merge_img.shape) != (B, 3, P, Q) or tuple(bg_img.shape) != (1, 3, P, Q):
+            raise ValueError("fused_data_losses: merge_img must be [B,3,P,P] and bg_img [1,3,P,P], got %s and %s"
+                             % (tuple(merge_img.shape), tuple(bg_img.shape)))
+        if tuple(gt_rgb.shape) != tuple(merge_img.shape) or tuple(mask.shape) != (B, 1, P, Q):
+            raise ValueError("fused_data_losses: gt_rgb must match merge_img and mask be [B,1,P,P], got %s and %s"
+                             % (tuple(gt_rgb.shape), tuple(mask.shape)))
+        if not (merge_img.is_cuda and all(t.device == merge_img.device for t in (bg_img, gt_rgb, mask))):
+            raise ValueError("fused_data_losses: all tensors must live on the same GPU (no CPU fallback)")
         m, b, g, k = (t.detach().float().contiguous() for t in (merge_img, bg_img, gt_rgb, mask))
         acc = torch.empty(6, dtype=torch.float32, device=m.device)
         terms = torch.empty(3, dtype=torch.float32, device=m.device)
-        check(lib().n3dt_loss_fwd(B, P * P, ops._ptr(m), ops._ptr(b), ops._ptr(g), ops._ptr(k), ctypes.c_float(bg_value),
+        check(lib().n3dt_loss_fwd(B, P * Q, ops._ptr(m), ops._ptr(b), ops._ptr(g), ops._ptr(k), ctypes.c_float(bg_value),
                                   ops._ptr(acc), ops._ptr(terms), ops._stream()), "n3dt_loss_fwd")
         ctx.keep, ctx.bg_value = (m, b, g, k, acc), bg_value
         return terms
@@ -53,9 +63,9 @@ class _FusedDataLoss(torch.autograd.Function):
         from . import ops
         from ._lib import lib, check
         m, b, g, k, acc = ctx.keep
-        B, _, P, _ = m.shape
-        d_m, d_b = torch.empty_like(m), torch.empty_like(b)
-        check(lib().n3dt_loss_bwd(B, P * P, ops._ptr(m), ops._ptr(b), ops._ptr(g), ops._ptr(k), ctypes.c_float(ctx.bg_value),
+        B, _, P, Q = m.shape
+        d_m, d_b = torch.empty_like(m), torch.zeros_like(b)
+        check(lib().n3dt_loss_bwd(B, P * Q, ops._ptr(m), ops._ptr(b), ops._ptr(g), ops._ptr(k), ctypes.c_float(ctx.bg_value),
                                   ops._ptr(acc), ops._ptr(g_terms.float().contiguous()), ops._ptr(d_m), ops._ptr(d_b),
                                   ops._stream()), "n3dt_loss_bwd")
         return d_m, d_b, None, None, None

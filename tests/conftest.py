@@ -51,8 +51,11 @@ def synthetic_case(m, **kw):
     """Rebuild (opt, state_dict, inputs) of a fixture from its manifest and verify the weight checksum."""
     from n3dt import synthetic as syn
     opt = options_from_manifest(m)
-    sd = syn.make_state_dict(opt, seed=m.get("weights_seed", 0), bg_noise=m.get("bg_noise", 0.0),
-                             hier_sampling=bool(m.get("hier_sampling", False)), **kw)
+    if m.get("weights_kind") == "contrast":
+        sd = syn.contrast_state_dict(opt, seed=m.get("weights_seed", 0))
+    else:
+        sd = syn.make_state_dict(opt, seed=m.get("weights_seed", 0), bg_noise=m.get("bg_noise", 0.0),
+                                 hier_sampling=bool(m.get("hier_sampling", False)), **kw)
     cs = syn.state_dict_checksum(sd)
     ref = m.get("weights_checksum")
     if ref is not None and not kw:

@@ -161,3 +161,25 @@ def test_stream_hazard_scanner_flags_scalar_and_flat_accesses(tmp_path):
         f.write_text("_Z1kv:\n" + body + "\ts_endpgm\n")
         found = mod.scan_inflight(str(f))
         assert (len(found) == 0) == (name == "waited"), (name, found)
+
+
+def test_shipped_stream_kernels_pass_the_hazard_gate():
+    """The static gate on the SHIPPED build: the Makefile keeps the device assembly of the very compile that produced the
+    objects linked into libn3dt.so (build/<name>.s, same FLAGS); scan() and scan_inflight() must find nothing in any
+    kernel of it -- every tiling of the fused render kernel (1, 2 and the 16x16x32 one), the training forward / dX chain /
+    weight-gradient kernels and every instantiation of the renderer's fused block kernel."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_smem_hazard", os.path.join(REPO, "tools", "check_smem_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    findings, kernels = mod.check_shipped(verbose=False)
+    assert not findings, "\n".join(findings)
+    # the scan saw the kernels it is there for
+    assert len(kernels["nerf_fwd_x16"]) >= 4 and len(kernels["nerf_fwd_x16b"]) >= 2
+    assert len(kernels["neural_render"]) >= 8 and len(kernels["train_mlp"]) >= 2
+    names = " ".join(sum(kernels.values(), []))
+    for k in ("nerf_fwd_x16_kernel", "nerf_fwd_x16_train_kernel", "nerf_fwd_x16b_kernel", "nr_level_x16_kernel", "nerf_bwd_x16_kernel"):
+        assert k in names, k
+    # and it is the shipped flags it saw
+    flags = open(os.path.join(REPO, "nerf-3dtalker-code_amd", "build", "nerf_fwd_x16.flags")).read()
+    assert "-ffp-contract=off" in flags and "-fPIC" in flags and "gfx950" in flags

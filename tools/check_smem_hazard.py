@@ -9,17 +9,18 @@ kernel arguments lazily; kernels pin what they need up front (x16_pin) and this 
 A second check (scan_inflight) looks for anything that reads or writes a fragment's registers while its LDS read is still
 in flight.
 
-usage: python tools/check_smem_hazard.py        (compiles the four sources to assembly, ~5 min; exit code 1 on a finding)
+The scan runs on build/<name>.s, the device assembly the Makefile keeps from the compile that produced the shipped objects
+(same FLAGS, -save-temps=obj), for every source file: all tilings and the training kernels included.
+
+usage: python tools/check_smem_hazard.py   or   make -C nerf-3dtalker-code_amd check     (exit code 1 on a finding)
 """
 import os
 import re
 import subprocess
 import sys
-import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(REPO, "nerf-3dtalker-code_amd")
-SOURCES = ["nerf_fwd_x16", "nerf_fwd_x16b", "train_mlp", "neural_render"]
 
 
 def scan(path):
@@ -93,22 +94,55 @@ def scan_inflight(path):
     return bad
 
 
+def stream_kernels(path):
+    """Names of the kernels in an assembly file that contain an inline-asm fragment read (the stream kernels)."""
+    names, name = [], None
+    lines = open(path).read().split("\n")
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            name = m.group(1)
+        elif name and "ds_read_b128" in l and "ASMSTART" in lines[i - 1] and name not in names:
+            names.append(name)
+    return names
+
+
+def shipped_assembly():
+    """build/<name>.s: the device assembly the Makefile keeps from the very compile that produced the shipped objects
+    (-save-temps=obj, same FLAGS).  (Re)builds first, so a stale or missing file cannot be scanned by mistake."""
+    subprocess.run(["make", "-s", "-j", str(min(8, os.cpu_count() or 1)), "-C", PKG], check=True)
+    build = os.path.join(PKG, "build")
+    files = sorted(os.path.join(build, f) for f in os.listdir(build) if f.endswith(".s"))
+    lib = os.path.join(PKG, "lib", "libn3dt.so")
+    for f in files:
+        if os.path.getmtime(f) > os.path.getmtime(lib) + 1.0:
+            raise RuntimeError("%s is newer than libn3dt.so: the library was not linked from it" % f)
+    return files
+
+
+def check_shipped(verbose=True):
+    """Scan every kernel of the shipped build.  Returns (findings, {file: [stream kernel names]})."""
+    findings, kernels = [], {}
+    for path in shipped_assembly():
+        src = os.path.basename(path)[:-2]
+        kernels[src] = stream_kernels(path)
+        for name, off, ins in scan(path):
+            findings.append("%s: %s: scalar/flat access %d lines after the first stream read: %s" % (src, name, off, ins))
+        for name, off, ins in scan_inflight(path):
+            findings.append("%s: %s: touches a fragment still in flight (read issued %d lines earlier): %s" % (src, name, off, ins))
+        if verbose:
+            print("%s: scanned (%d stream kernels)" % (src, len(kernels[src])))
+    return findings, kernels
+
+
 def main():
-    rc = 0
-    with tempfile.TemporaryDirectory() as tmp:
-        for src in SOURCES:
-            out = os.path.join(tmp, src + ".s")
-            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(REPO, "include"),
-                   "-I" + os.path.join(PKG, "csrc"), "-S", "--cuda-device-only", os.path.join(PKG, "csrc", src + ".hip"), "-o", out]
-            subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
-            for name, off, ins in scan(out):
-                print("%s: %s: scalar/flat access %d lines after the first stream read: %s" % (src, name, off, ins))
-                rc = 1
-            for name, off, ins in scan_inflight(out):
-                print("%s: %s: touches a fragment still in flight (read issued %d lines earlier): %s" % (src, name, off, ins))
-                rc = 1
-            print("%s: scanned" % src)
-    return rc
+    findings, kernels = check_shipped()
+    for f in findings:
+        print(f)
+    if not any(kernels.values()):
+        print("no stream kernel found in build/*.s -- the scan did not see the shipped code")
+        return 1
+    return 1 if findings else 0
 
 
 if __name__ == "__main__":

@@ -394,6 +394,142 @@ def gen_hier(HeadNeRFNet, name, fs, nc, nf, pred, B, mode):
     }))
 
 
+def install_caller_standins():
+    """Modules the reference's CALLER-side helpers import at module level but never use on the code paths driven here
+    (Utils/RenderUtils.py:1-18, Utils/HeadNeRFLossUtils.py:1-6): turtle (needs tkinter), cv2, torchvision, face_alignment.
+    cv2.cvtColor / imwrite are called by render_novel_views only to dump PNGs to a hard-coded path: no-ops here."""
+    for name in ("turtle", "cv2", "torchvision", "face_alignment"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["turtle"].color = None
+    cv2 = sys.modules["cv2"]
+    cv2.COLOR_BGR2RGB = 4
+    cv2.cvtColor = lambda img, code: img
+    cv2.imwrite = lambda path, img: True
+
+
+def gen_render_utils(HeadNeRFNetNoAudio):
+    """the reference's own RenderUtils (ray grid, intrinsics scaling, orbit cameras, base camera) and its
+    serial novel-view / morphing sweeps (Utils/RenderUtils.py:31-157), which call the net WITHOUT audiostyle and
+    therefore only run against the audio-less `_yuan` network."""
+    import tempfile
+    install_caller_standins()
+    sys.path.insert(0, REF)
+    from Utils.RenderUtils import RenderUtils as RefRenderUtils
+    inv32 = syn.inv_intrinsics(32, 1)[0]
+    arrays = {"inv_inmat_32": np32(inv32)}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "ConfigFiles"))
+        with open(os.path.join(tmp, "ConfigFiles", "cam_inmat_info_32x32.json"), "w") as f:
+            json.dump({"inv_inmat": inv32.tolist()}, f)  # the file the reference reads is not shipped (SURVEY header)
+        os.chdir(tmp)
+        try:
+            for fs, views in ((32, 45), (64, 7), (8, 5)):
+                opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": fs * 4, "num_sample_coarse": 8})
+                ru = RefRenderUtils(views, torch.device("cpu"), opt)
+                k = "fs%d_v%d." % (fs, views)
+                arrays[k + "ray_xy"] = np32(ru.ray_xy)
+                arrays[k + "ray_uv"] = np32(ru.ray_uv)
+                arrays[k + "inv_inmat"] = np32(ru.inv_inmat)
+                arrays[k + "Rmats"] = np32(torch.cat([c["batch_Rmats"] for c in ru.cam_info_list]))
+                arrays[k + "Tvecs"] = np32(torch.cat([c["batch_Tvecs"] for c in ru.cam_info_list]))
+                arrays[k + "base_R"] = np32(ru.base_cam_info["batch_Rmats"])
+                arrays[k + "base_T"] = np32(ru.base_cam_info["batch_Tvecs"])
+            # the sweeps themselves, on the tiny geometry (last `ru`/`opt`: fs 8 -> 32, 5 views)
+            sdn = syn.make_state_dict(opt, seed=4, audio_dim=0, bg_noise=0.1)
+            net = HeadNeRFNetNoAudio(opt, include_vd=False, hier_sampling=False)
+            net.load_state_dict(sdn, strict=True)
+            sh, ap, _ = syn.latents(2, 179, 127, 0)
+            code1 = {"bg_code": None, "shape_code": sh[0:1], "appea_code": ap[0:1]}
+            code2 = {"bg_code": None, "shape_code": sh[1:2], "appea_code": ap[1:2]}
+            arrays["sweep.novel_views_u8"] = np.stack(ru.render_novel_views(net, code1))
+            arrays["sweep.morph_u8"] = np.stack(ru.render_morphing_res(net, code1, code2, 4))
+        finally:
+            os.chdir(cwd)
+    save("render_utils", arrays, manifest_base("render_utils", opt, {
+        "what": "Utils/RenderUtils.py RenderUtils: build_base_info / build_cam_info values for (fs, view_num) in "
+                "(32,45), (64,7), (8,5); render_novel_views (5 views) and render_morphing_res (4 steps) uint8 frames at fs 8 -> 32 "
+                "with the audio-less net (weights seed 4, latents of frames 0 and 1)",
+        "intrinsics": "ConfigFiles/cam_inmat_info_32x32.json is not shipped: a temporary file holding n3dt.synthetic.inv_intrinsics(32)",
+        "weights_checksum_noaudio": syn.state_dict_checksum(sdn),
+    }))
+
+
+def gen_loss():
+    """HeadNeRFLossUtils.calc_total_loss(use_vgg_loss=False) of the reference (Utils/HeadNeRFLossUtils.py:
+    125-156, 196-236) on images with NaNs, soft mask values on both sides of 0.5, and its gradients."""
+    install_caller_standins()
+    sys.path.insert(0, REF)
+    from Utils.HeadNeRFLossUtils import HeadNeRFLossUtils
+    arrays = {}
+    cases = []
+    for name, B, P, bg_type, seed in (("a", 2, 32, "white", 21), ("b", 3, 16, "black", 22), ("c", 1, 64, "white", 23)):
+        g = torch.Generator().manual_seed(seed)
+        merge = torch.rand(B, 3, P, P, generator=g)
+        merge.view(-1)[torch.randperm(merge.numel(), generator=g)[:7]] = float("nan")
+        bg = torch.rand(1, 3, P, P, generator=g)
+        gt = torch.rand(B, 3, P, P, generator=g)
+        mask = torch.rand(B, 1, P, P, generator=g)
+        mask.view(-1)[:5] = 0.5  # the boundary value belongs to the head (>= 0.5)
+        merge.requires_grad_(True)
+        bg.requires_grad_(True)
+        lu = HeadNeRFLossUtils(bg_type=bg_type, use_vgg_loss=False)
+        res = lu.calc_total_loss(None, None, {"coarse_dict": {"merge_img": merge, "bg_img": bg}}, gt, mask, None)
+        res["total_loss"].backward()
+        k = name + "."
+        arrays.update({k + "merge_img": np32(merge), k + "bg_img": np32(bg), k + "gt": np32(gt), k + "mask": np32(mask),
+                       k + "terms": np.array([res["bg_loss"].item(), res["head_loss"].item(), res["nonhaed_loss"].item(),
+                                              res["total_loss"].item()], dtype=np.float64),
+                       k + "d_merge": np32(merge.grad), k + "d_bg": np32(bg.grad)})
+        cases.append({"name": name, "batch": B, "size": P, "bg_type": bg_type, "seed": seed})
+    opt = BaseOptions({"featmap_size": 8, "featmap_nc": 256, "pred_img_size": 32, "num_sample_coarse": 8})
+    save("loss", arrays, manifest_base("loss", opt, {
+        "what": "Utils/HeadNeRFLossUtils.py HeadNeRFLossUtils(bg_type, use_vgg_loss=False).calc_total_loss: bg / head / "
+                "nonhead terms, total, and autograd gradients w.r.t. merge_img and bg_img", "cases": cases}))
+
+
+def gen_contrast(HeadNeRFNet):
+    """A fixture that stresses the 16-bit modes: the density head scaled so that alpha saturates on
+    part of the rays and stays small elsewhere, feature magnitudes O(10), fs 32 -> 256, 64 samples, two heads."""
+    fs, ns, pred, B = 32, 64, 256, 2
+    opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": pred, "num_sample_coarse": ns})
+    sd = contrast_state_dict(opt)
+    net = build_ref_net(HeadNeRFNet, opt, sd)
+    inp = syn.frame_inputs(opt, B, yaw_range=0.3)
+    with torch.no_grad():
+        coarse, s = run_seams(net, inp, "test")
+    w = s["color"][3]
+    dens = s["mlp"][1]
+    alpha = 1.0 - torch.exp(-dens * s["sample"]["z_dists"])
+    img = np32(coarse["merge_img"])
+    rays = slice(0, fs * fs, 8)
+    arrays = {
+        "ray_index_step": np.int64(8),
+        "density": np32(dens[:, :, rays]), "fg_feat": np32(s["color"][0][:, :, rays]), "bg_alpha": np32(s["color"][1]),
+        "weight": np32(w[:, :, rays]), "merge_img_q16": q16(img), "bg_img_q16": q16(np32(coarse["bg_img"])),
+        "merge_featmap": np32(s["merge_featmap"][:, :, ::4, ::4]),
+    }
+    stats = {
+        "alpha_max": float(alpha.max()), "frac_samples_alpha_gt_0.99": float((alpha > 0.99).float().mean()),
+        "frac_rays_bg_alpha_lt_0.01": float((s["color"][1] < 0.01).float().mean()),
+        "frac_rays_bg_alpha_gt_0.5": float((s["color"][1] > 0.5).float().mean()),
+        "feat_abs_max": float(s["mlp"][0].abs().max()), "fg_feat_abs_max": float(s["color"][0].abs().max()),
+        "density_max": float(dens.max()),
+    }
+    print("contrast stats:", stats)
+    save("contrast", arrays, manifest_base("contrast", opt, {
+        "batch": B, "mode": "test", "weights_seed": 0, "bg_noise": 0.1, "yaw_range": 0.3,
+        "weights_kind": "contrast",
+        "weights": "n3dt.synthetic.contrast_state_dict (seed 0; density head x400 with bias -60, RGB_layer_2 x40)",
+        "weights_checksum": syn.state_dict_checksum(sd), "stats": stats,
+    }))
+
+
+def contrast_state_dict(opt):
+    return syn.contrast_state_dict(opt)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -412,6 +548,9 @@ def main():
         "cfg4": lambda: gen_cfg(HeadNeRFNet, "cfg4", fs=32, ns=64, pred=256, ray_step=16, B=4, mode="train"),
         "hier_test": lambda: gen_hier(HeadNeRFNet, "hier_test", fs=8, nc=64, nf=128, pred=32, B=1, mode="test"),
         "hier_train": lambda: gen_hier(HeadNeRFNet, "hier_train", fs=8, nc=16, nf=24, pred=32, B=2, mode="train"),
+        "render_utils": lambda: gen_render_utils(HeadNeRFNetNoAudio),
+        "loss": gen_loss,
+        "contrast": lambda: gen_contrast(HeadNeRFNet),
     }
     for k, fn in jobs.items():
         if args.only is None or k in args.only:
