@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define N3DT_ABI_VERSION 2
+#define N3DT_ABI_VERSION 3
 
 /* arithmetic type of the MLP contraction */
 #define N3DT_F32 0  /* v_mfma_f32_16x16x4_f32, exact fp32: the <=1e-3 RGB parity mode */
@@ -243,6 +243,34 @@ int n3dt_loss_bwd(int batch, int pixels, const float* merge_img, const float* bg
 
 /* [C, N_r] (NCHW parameter) -> [N_r, C]; used to feed bg_featmap to the renderer */
 int n3dt_chw_to_hwc(int C, int n, const float* src, float* dst, void* stream);
+
+/* ---- per-call host overhead: input staging + hipGraph replay ----------------------------------------
+ * The reference's call shapes are small batches (validation B=1 talker_trainer.py:1119, fitting B=1 x 300 iterations
+ * FittingSingleImage_new.py:887): a forward is ~17 short kernels and launch gaps are a quarter of the step.  Every entry
+ * point above allocates nothing and only enqueues on `stream`, so a whole forward can be recorded once into a hipGraph
+ * and replayed with ONE launch.  A replay reads the addresses recorded at capture time: the caller keeps static
+ * buffers and refreshes them with n3dt_stage_inputs (one small kernel instead of one copy per tensor).
+ *
+ * n3dt_stage_inputs: n <= N3DT_STAGE_MAX copies src[i] -> dst[i] of count[i] floats in one launch.  Entry 0 may be a
+ * strided 3-D view (batch_xy [B,2,N_r] with the strides the caller holds it in, e.g. an expand()ed grid): set
+ * view_dims / view_strides (elements) and count[0] = product of view_dims; leave view_dims[0] = 0 for a flat copy. */
+#define N3DT_STAGE_MAX 12
+typedef struct N3dtStageCopy {
+    const float* src[N3DT_STAGE_MAX];
+    float* dst[N3DT_STAGE_MAX];
+    int64_t count[N3DT_STAGE_MAX];
+    int64_t view_dims[3], view_strides[3];
+    int32_t n;
+} N3dtStageCopy;
+int n3dt_stage_inputs(const N3dtStageCopy* st, void* stream);
+
+/* hipStreamBeginCapture (relaxed mode: other threads / streams are unaffected) ... hipStreamEndCapture +
+ * hipGraphInstantiate.  Between begin and end, enqueue the n3dt_* calls of one forward on `stream`; nothing runs until
+ * n3dt_graph_launch.  *graph_out is an opaque handle owned by the library until n3dt_graph_destroy. */
+int n3dt_graph_begin(void* stream);
+int n3dt_graph_end(void* stream, void** graph_out);
+int n3dt_graph_launch(void* graph, void* stream);
+int n3dt_graph_destroy(void* graph);
 
 /* ---- measurement hook (bench.py only) ---------------------------------------------------------
  * While enabled, every n3dt_render_fwd brackets its fused MLP kernel launch (the roofline kernel,

@@ -1,10 +1,13 @@
 // extern "C" entry points of libn3dt.so (declared in include/n3dt.h).
 // Host-side only: validates geometry, carves the caller's workspace and enqueues kernels on the
-// caller's stream.  No allocation, no synchronisation, no global mutable state.
+// caller's stream.  No allocation, no synchronisation; the only mutable global state is the opt-in
+// measurement hook (n3dt_prof_*, mutex-guarded).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
 
 #include "../../include/n3dt.h"
 #include "n3dt_layout.h"
@@ -59,6 +62,7 @@ void n3dt_launch_nr_train_fwd(const N3dtGeom*, int, const N3dtRenderParams*, con
 void n3dt_launch_nr_bwd(const N3dtGeom*, int, const N3dtRenderParams*, const N3dtRenderGrads*, const float*, const float*, const float*,
                         float*, float*, int, hipStream_t);
 void n3dt_launch_neural_render(const N3dtGeom*, int, int, const N3dtRenderParams*, const float*, float*, float*, hipStream_t);
+void n3dt_launch_stage(const N3dtStageCopy*, hipStream_t);
 }
 
 static thread_local char g_err[256] = "";
@@ -124,24 +128,34 @@ static RenderCarve render_carve(const N3dtGeom* g, int precision) {
 }
 
 // ---- opt-in measurement hook (see n3dt.h) ---------------------------------------------------
+static std::mutex g_prof_mu;
 static hipEvent_t* g_prof_ev = nullptr;  // 2 * g_prof_cap events
 static int g_prof_cap = 0, g_prof_n = 0;
 
-extern "C" int n3dt_prof_enable(int max_records) {
-    for (int i = 0; i < 2 * g_prof_cap; ++i) (void)hipEventDestroy(g_prof_ev[i]);
+static void prof_free_locked(int created) {
+    for (int i = 0; i < created; ++i) (void)hipEventDestroy(g_prof_ev[i]);
     delete[] g_prof_ev;
     g_prof_ev = nullptr;
     g_prof_cap = g_prof_n = 0;
+}
+
+extern "C" int n3dt_prof_enable(int max_records) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    prof_free_locked(2 * g_prof_cap);
     if (max_records <= 0) return N3DT_OK;
     g_prof_ev = new hipEvent_t[2 * (size_t)max_records];
     for (int i = 0; i < 2 * max_records; ++i)
-        if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) return fail(N3DT_EHIP, "n3dt_prof_enable: hipEventCreate failed");
+        if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) {
+            prof_free_locked(i);  // the events created so far do not leak
+            return fail(N3DT_EHIP, "n3dt_prof_enable: hipEventCreate failed");
+        }
     g_prof_cap = max_records;
     return N3DT_OK;
 }
 
 extern "C" int n3dt_prof_collect(float* ms_out, int capacity, int* n_out) {
     if (!ms_out || !n_out) return fail(N3DT_EINVAL, "n3dt_prof_collect: NULL argument");
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     int n = g_prof_n < capacity ? g_prof_n : capacity;
     for (int i = 0; i < n; ++i) {
         if (hipEventSynchronize(g_prof_ev[2 * i + 1]) != hipSuccess) return fail(N3DT_EHIP, "n3dt_prof_collect: sync failed");
@@ -197,7 +211,9 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
     float* part = (float*)(ws + c.part);
     float* wlocal = (float*)(ws + c.wlocal);
     n3dt_launch_fold(g, p, shape, appea, audio, fold, precision != N3DT_F32, s);
-    const bool prof = g_prof_cap > 0 && g_prof_n < g_prof_cap;
+    std::unique_lock<std::mutex> prof_lock(g_prof_mu, std::defer_lock);
+    if (g_prof_cap > 0) prof_lock.lock();  // the unlocked read is the hook's documented contract: enabled from one thread, while idle
+    const bool prof = prof_lock.owns_lock() && g_prof_n < g_prof_cap;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_n], s);
     if (precision == N3DT_F32)
         n3dt_launch_nerf_fwd_f32(g, p, packed_mlp, fold, xy, R, T, Kinv, t_rand, part, weight ? wlocal : nullptr, s);
@@ -210,6 +226,7 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
         (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], s);
         ++g_prof_n;
     }
+    if (prof_lock.owns_lock()) prof_lock.unlock();
     const float* tail = (const float*)((const unsigned char*)packed_mlp + n3dt_packed_tail_offset(precision));
     float* bghwc = (float*)(ws + c.bghwc);
     if (merge_feat) n3dt_launch_chw_to_hwc(g->feat_nc, g->n_rays, bg_featmap, bghwc, s);  // [C][N_r] parameter -> [N_r][C]
@@ -444,4 +461,69 @@ extern "C" int n3dt_loss_bwd(int batch, int pixels, const float* merge_img, cons
         return fail(N3DT_EINVAL, "n3dt_loss_bwd: bad argument");
     n3dt_launch_loss_bwd(batch, pixels, merge_img, bg_img, gt, mask, bg_value, acc, g, d_merge, d_bg, (hipStream_t)stream);
     return check_hip("n3dt_loss_bwd");
+}
+
+// ---- input staging + hipGraph replay (see n3dt.h) -------------------------------------------------------------
+extern "C" int n3dt_stage_inputs(const N3dtStageCopy* st, void* stream) {
+    if (!st || st->n < 1 || st->n > N3DT_STAGE_MAX) return fail(N3DT_EINVAL, "n3dt_stage_inputs: bad entry count");
+    for (int i = 0; i < st->n; ++i)
+        if (!st->src[i] || !st->dst[i] || st->count[i] < 1) return fail(N3DT_EINVAL, "n3dt_stage_inputs: NULL pointer or empty entry");
+    if (st->view_dims[0] > 0) {
+        if (st->view_dims[1] < 1 || st->view_dims[2] < 1 || st->view_dims[0] * st->view_dims[1] * st->view_dims[2] != st->count[0])
+            return fail(N3DT_EINVAL, "n3dt_stage_inputs: view_dims do not multiply to count[0]");
+        for (int d = 0; d < 3; ++d)
+            if (st->view_strides[d] < 0) return fail(N3DT_EINVAL, "n3dt_stage_inputs: negative stride");
+    }
+    n3dt_launch_stage(st, (hipStream_t)stream);
+    return check_hip("n3dt_stage_inputs");
+}
+
+struct N3dtGraph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+extern "C" int n3dt_graph_begin(void* stream) {
+    (void)hipGetLastError();
+    if (hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(N3DT_EHIP, "n3dt_graph_begin: hipStreamBeginCapture failed (the legacy NULL stream cannot be captured)");
+    }
+    return N3DT_OK;
+}
+
+extern "C" int n3dt_graph_end(void* stream, void** graph_out) {
+    if (!graph_out) return fail(N3DT_EINVAL, "n3dt_graph_end: NULL argument");
+    *graph_out = nullptr;
+    hipGraph_t graph = nullptr;
+    if (hipStreamEndCapture((hipStream_t)stream, &graph) != hipSuccess || !graph) {
+        (void)hipGetLastError();
+        return fail(N3DT_EHIP, "n3dt_graph_end: hipStreamEndCapture failed (a call inside the capture was not capturable)");
+    }
+    hipGraphExec_t exec = nullptr;
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipGraphDestroy(graph);
+        return fail(N3DT_EHIP, "n3dt_graph_end: hipGraphInstantiate failed");
+    }
+    *graph_out = new N3dtGraph{graph, exec};
+    return N3DT_OK;
+}
+
+extern "C" int n3dt_graph_launch(void* graph, void* stream) {
+    if (!graph) return fail(N3DT_EINVAL, "n3dt_graph_launch: NULL graph");
+    if (hipGraphLaunch(((N3dtGraph*)graph)->exec, (hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(N3DT_EHIP, "n3dt_graph_launch: hipGraphLaunch failed");
+    }
+    return N3DT_OK;
+}
+
+extern "C" int n3dt_graph_destroy(void* graph) {
+    if (!graph) return N3DT_OK;
+    N3dtGraph* g = (N3dtGraph*)graph;
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return N3DT_OK;
 }

@@ -555,3 +555,29 @@ extern "C" void n3dt_launch_fine_sample(const N3dtGeom* g, int n_fine, const flo
     const size_t lds = sizeof(float) * ((size_t)g->n_samples * 2 - 1 + g->n_samples + n_fine + 1);
     hipLaunchKernelGGL(fine_sample_kernel, dim3((unsigned)rays), dim3(64), lds, stream, *g, n_fine, weight, T, t_rand, u, z_planes);
 }
+
+// ---- n3dt_stage_inputs: up to N3DT_STAGE_MAX small copies in one launch (blockIdx.y = entry) ------------------------
+__global__ void stage_kernel(N3dtStageCopy st) {
+    const int e = blockIdx.y;
+    if (e >= st.n) return;
+    const float* __restrict__ src = st.src[e];
+    float* __restrict__ dst = st.dst[e];
+    const long n = st.count[e];
+    const bool view = e == 0 && st.view_dims[0] > 0;
+    const long d1 = st.view_dims[1], d2 = st.view_dims[2];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        long j = i;
+        if (view) {
+            const long i2 = i % d2, i1 = (i / d2) % d1, i0 = i / (d2 * d1);
+            j = i0 * st.view_strides[0] + i1 * st.view_strides[1] + i2 * st.view_strides[2];
+        }
+        dst[i] = src[j];
+    }
+}
+
+extern "C" void n3dt_launch_stage(const N3dtStageCopy* st, hipStream_t stream) {
+    long most = 1;
+    for (int i = 0; i < st->n; ++i) most = st->count[i] > most ? st->count[i] : most;
+    const int bx = (int)((most + 255) / 256 < 64 ? (most + 255) / 256 : 64);
+    hipLaunchKernelGGL(stage_kernel, dim3(bx, st->n), dim3(256), 0, stream, *st);
+}

@@ -50,7 +50,16 @@ EXPORTS = [
     "n3dt_neural_render_train_saved_bytes", "n3dt_neural_render_train_workspace_bytes",
     "n3dt_neural_render_train_fwd", "n3dt_neural_render_bwd", "n3dt_loss_fwd", "n3dt_loss_bwd", "n3dt_fine_sample",
     "n3dt_img_to_uint8", "n3dt_sample_points", "n3dt_embed", "n3dt_mlp_points_workspace_bytes", "n3dt_mlp_points", "n3dt_composite",
+    "n3dt_stage_inputs", "n3dt_graph_begin", "n3dt_graph_end", "n3dt_graph_launch", "n3dt_graph_destroy",
 ]
+
+STAGE_MAX = 12
+
+
+class Stage(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p * STAGE_MAX), ("dst", ctypes.c_void_p * STAGE_MAX), ("count", ctypes.c_int64 * STAGE_MAX),
+                ("view_dims", ctypes.c_int64 * 3), ("view_strides", ctypes.c_int64 * 3), ("n", ctypes.c_int32)]
+
 
 _LIB = None
 
@@ -123,10 +132,31 @@ def lib():
     L.n3dt_mlp_points.argtypes = [gp, sz, mp] + [vp] * 5 + [vp, sz, vp]
     L.n3dt_composite.restype = ci
     L.n3dt_composite.argtypes = [ci, ci, ci, ci] + [vp] * 8 + [vp]
-    if L.n3dt_abi_version() != 2:
+    L.n3dt_stage_inputs.restype = ci
+    L.n3dt_stage_inputs.argtypes = [ctypes.POINTER(Stage), vp]
+    L.n3dt_graph_begin.restype = ci
+    L.n3dt_graph_begin.argtypes = [vp]
+    L.n3dt_graph_end.restype = ci
+    L.n3dt_graph_end.argtypes = [vp, ctypes.POINTER(vp)]
+    L.n3dt_graph_launch.restype = ci
+    L.n3dt_graph_launch.argtypes = [vp, vp]
+    L.n3dt_graph_destroy.restype = ci
+    L.n3dt_graph_destroy.argtypes = [vp]
+    if L.n3dt_abi_version() != 3:
         raise N3dtError("libn3dt.so ABI version mismatch")
     _LIB = L
     return L
+
+
+PROF_ACTIVE = False
+
+
+def prof_enable(max_records):
+    """The measurement hook of bench.py (n3dt_prof_enable).  While it is active forward() does not replay hipGraphs:
+    the hook's events are recorded by the launching call, which a replay never executes."""
+    global PROF_ACTIVE
+    check(lib().n3dt_prof_enable(int(max_records)), "n3dt_prof_enable")
+    PROF_ACTIVE = max_records > 0
 
 
 def check(rc, what):

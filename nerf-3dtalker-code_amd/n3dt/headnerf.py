@@ -11,6 +11,7 @@ Sub-modules keep the reference's attribute names (sample_func, vp_encoder, fg_CD
 calc_color_func, neural_render) so the inner seams stay addressable.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -156,10 +157,11 @@ class NeuralRenderer(nn.Module):
             flat += [m.weight, m.bias]
         return _NeuralRenderFn.apply(self, featmap_hwc, *flat)
 
-    def render_hwc(self, featmap_hwc, precision="fp32"):
-        """[nb, fs, fs, C] ray-major feature maps -> [nb, 3, P, P]"""
+    def render_hwc(self, featmap_hwc, precision="fp32", img=None, ws=None):
+        """[nb, fs, fs, C] ray-major feature maps -> [nb, 3, P, P] (img / ws: caller-owned buffers, nothing is allocated)"""
         nb = featmap_hwc.shape[0]
-        return ops.neural_render_fwd(self._geom(nb), nb, self._rparams(), featmap_hwc.contiguous(), _lib.PRECISIONS[precision])
+        assert featmap_hwc.is_contiguous()
+        return ops.neural_render_fwd(self._geom(nb), nb, self._rparams(), featmap_hwc, _lib.PRECISIONS[precision], img=img, ws=ws)
 
     def forward(self, x):
         """x: [nb, C, fs, fs] like the reference module."""
@@ -167,7 +169,7 @@ class NeuralRenderer(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return self.render_hwc_train(x.permute(0, 2, 3, 1).contiguous())
         hwc = torch.stack([ops.chw_to_hwc(x[i].contiguous(), C, fs * fs) for i in range(nb)]).view(nb, fs, fs, C)
-        return self.render_hwc(hwc)
+        return self.render_hwc(hwc.contiguous())
 
 
 
@@ -304,7 +306,7 @@ class CalcRayColor(nn.Module):
 
 class HeadNeRFNet(nn.Module):
     def __init__(self, opt, include_vd, hier_sampling, include_gaze=False, eye_gaze_dim=2, audio_dim=64, precision="fp32",
-                 train_precision="fp32"):
+                 train_precision="fp32", use_graph=None, graph_static_outputs=False):
         super().__init__()
         # hier_sampling=True: the reference builds FineSample + a second MLP (HeadNeRFNet.py:67-74) but its call site omits
         # two arguments (:182-185) and raises TypeError; here the fine pass runs, with those arguments supplied
@@ -323,6 +325,12 @@ class HeadNeRFNet(nn.Module):
         self._build_tool_funcs()
         self.neural_render.train_precision = train_precision
         self._pack_cache = {}
+        # mode="test" forwards are recorded once per call shape into a hipGraph and replayed with one launch (see
+        # _forward_graph); N3DT_GRAPH=0 / use_graph=False keeps the kernel-by-kernel path.  graph_static_outputs=True
+        # returns views of the graph's own output buffer (valid until the next forward of the same shape) instead of a copy.
+        self.use_graph = (os.environ.get("N3DT_GRAPH", "1") != "0") if use_graph is None else bool(use_graph)
+        self.graph_static_outputs = graph_static_outputs
+        self._graphs = {}
         # a (strict or not) load_state_dict replaces every weight: drop the packed copies
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_packed())
 
@@ -385,13 +393,14 @@ class HeadNeRFNet(nn.Module):
         ver = tuple((t.data_ptr(), t._version) for t in ws + bs)
         hit = self._pack_cache.get(key)
         if hit is None or hit[0] != ver:
-            hit = (ver, ops.pack_mlp(geom, precision, params, ws[0].device))
+            # re-pack INTO the existing buffer (stream-ordered): recorded hipGraphs keep reading a valid address
+            hit = (ver, ops.pack_mlp(geom, precision, params, ws[0].device, out=None if hit is None else hit[1]))
             self._pack_cache[key] = hit
         return hit[1]
 
     def render_features(self, batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
                         t_rand=None, want_depth=False, want_weight=False, want_merge=True, precision=None, merge_out=None,
-                        z_planes=None, want_fg=True):
+                        z_planes=None, want_fg=True, weight_out=None, workspace=None):
         """Rays -> composited feature map (seams a1..a7).  Outputs are ray-major [B, N_r, C].
         z_planes [B, N_r, N+1] (from fine_planes()): the hierarchical pass -- those planes, the fine network."""
         prec = _lib.PRECISIONS[precision or self.precision]
@@ -412,16 +421,16 @@ class HeadNeRFNet(nn.Module):
                              None if t_rand is None else ops._f32c(t_rand),
                              self.neural_render.bg_featmap.detach().view(self.featmap_nc, -1) if want_merge else None,
                              want_depth=want_depth, want_weight=want_weight, want_merge=want_merge, merge_out=merge_out,
-                             want_fg=want_fg)
+                             want_fg=want_fg, weight_out=weight_out, ws=workspace)
         return out
 
-    def fine_planes(self, batch_xy, coarse_weight, batch_Tvecs, t_rand=None, fine_u=None):
+    def fine_planes(self, batch_xy, coarse_weight, batch_Tvecs, t_rand=None, fine_u=None, out=None):
         """FineSample.forward (NetWorks/utils.py:211-263): coarse compositing weights [B, N_r, N_c] -> the
         N_c + N_f + 1 ascending sample planes of the fine pass.  fine_u [B*N_r, N_f+1]: the uniform samples of train mode."""
         B, _, n_r = batch_xy.size()
         xy = batch_xy if batch_xy.dtype == torch.float32 else batch_xy.float()
         return ops.fine_sample(self._geom(B, n_r, xy), self.num_sample_fine, ops._f32c(coarse_weight), ops._f32c(batch_Tvecs).view(B, 3),
-                               None if t_rand is None else ops._f32c(t_rand), None if fine_u is None else ops._f32c(fine_u))
+                               None if t_rand is None else ops._f32c(t_rand), None if fine_u is None else ops._f32c(fine_u), out=out)
 
     def _forward(self, for_train, batch_xy, batch_uv, audiostyle, bg_code, shape_code, appea_code, batch_Rmats,
                  batch_Tvecs, batch_inv_inmats, dist_expr, t_rand=None, fine_u=None):
@@ -441,27 +450,126 @@ class HeadNeRFNet(nn.Module):
         if needs_grad:
             return self._forward_train(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand,
                                        for_train=for_train, fine_u=fine_u)
-        # the merged maps (coarse, then fine) and the background map go through the 2-D renderer in one call; the
-        # render kernel writes its merged maps straight into that batch
+        if self._graph_usable(for_train, t_rand, batch_xy):
+            return self._forward_graph(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats)
         n_pass = 2 if self.hier_sampling else 1
         nb = n_pass * batch_size
         maps = torch.empty(nb + 1, fs, fs, C, dtype=torch.float32, device=batch_xy.device)
-        coarse = self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
-                                      t_rand=t_rand, want_weight=self.hier_sampling, want_merge=True, want_fg=False,
-                                      merge_out=maps[:batch_size].view(batch_size, fs * fs, C))
-        if self.hier_sampling:
-            if for_train and fine_u is None:  # the reference's torch.rand(num_temp, NFsample) (NetWorks/utils.py:227)
-                fine_u = torch.rand(batch_size * n_r, self.num_sample_fine + 1, device=batch_xy.device, dtype=torch.float32)
-            planes = self.fine_planes(batch_xy, coarse["weight"], batch_Tvecs, t_rand=t_rand, fine_u=fine_u)
-            self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
-                                 z_planes=planes, want_merge=True, want_fg=False,
-                                 merge_out=maps[batch_size:nb].view(batch_size, fs * fs, C))
-        ops.chw_to_hwc(self.neural_render.bg_featmap.detach().view(C, fs * fs), C, fs * fs, maps[nb].view(fs * fs, C))
-        imgs = self.neural_render.render_hwc(maps, self.precision)
+        if self.hier_sampling and for_train and fine_u is None:  # the reference's torch.rand(num_temp, NFsample) (NetWorks/utils.py:227)
+            fine_u = torch.rand(batch_size * n_r, self.num_sample_fine + 1, device=batch_xy.device, dtype=torch.float32)
+        imgs = self._infer_launch(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand, fine_u, maps)
+        return self._result(imgs, batch_size, nb)
+
+    def _result(self, imgs, batch_size, nb):
         res = {"coarse_dict": {"merge_img": imgs[:batch_size], "bg_img": imgs[nb:]}}
         if self.hier_sampling:
             res["fine_dict"] = {"merge_img": imgs[batch_size:nb], "bg_img": imgs[nb:]}
         return res
+
+    def _infer_launch(self, batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand, fine_u,
+                      maps, imgs=None, bufs=None):
+        """Enqueue one inference forward.  The merged maps (coarse, then fine) and the background map go through the 2-D
+        renderer in one call; the render kernel writes its merged maps straight into that batch.  With `imgs` and `bufs`
+        (caller-owned workspaces / intermediates) nothing is allocated, so the sequence can be recorded into a hipGraph."""
+        batch_size, _, n_r = batch_xy.size()
+        fs, C = self.featmap_size, self.featmap_nc
+        nb = (2 if self.hier_sampling else 1) * batch_size
+        bufs = bufs or {}
+        coarse = self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
+                                      t_rand=t_rand, want_weight=self.hier_sampling, want_merge=True, want_fg=False,
+                                      merge_out=maps[:batch_size].view(batch_size, fs * fs, C), weight_out=bufs.get("weight"),
+                                      workspace=bufs.get("render_ws"))
+        if self.hier_sampling:
+            planes = self.fine_planes(batch_xy, coarse["weight"], batch_Tvecs, t_rand=t_rand, fine_u=fine_u, out=bufs.get("planes"))
+            self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
+                                 z_planes=planes, want_merge=True, want_fg=False,
+                                 merge_out=maps[batch_size:nb].view(batch_size, fs * fs, C), workspace=bufs.get("fine_ws"))
+        ops.chw_to_hwc(self.neural_render.bg_featmap.detach().view(C, fs * fs), C, fs * fs, maps[nb].view(fs * fs, C))
+        return self.neural_render.render_hwc(maps, self.precision, img=imgs, ws=bufs.get("nr_ws"))
+
+    # ---- hipGraph replay of the inference forward ---------------------------------------------------------------
+    def _graph_usable(self, for_train, t_rand, batch_xy):
+        """Replay is used for plain mode="test" forwards (the reference's validation / fitting / sweep call shape,
+        talker_trainer.py:1119, Utils/RenderUtils.py:120) on a GPU, unless switched off (use_graph=False or N3DT_GRAPH=0) or
+        the bench's kernel-timing hook is active (its events belong to the launching call, which a replay never runs)."""
+        return (self.use_graph and not for_train and t_rand is None and batch_xy.is_cuda and not _lib.PROF_ACTIVE)
+
+    def _param_signature(self):
+        return tuple(p.data_ptr() for p in self.parameters())
+
+    def _forward_graph(self, batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats):
+        B, _, n_r = batch_xy.size()
+        dev = batch_xy.device
+        cur = torch.cuda.current_stream(dev)
+        key = (B, n_r, self.precision, dev.index, cur.cuda_stream)
+        sig = self._param_signature()
+        e = self._graphs.get(key)
+        if e is not None and e["sig"] != sig:  # parameters were re-allocated (e.g. .to(), a new bg_featmap): record again
+            ops.graph_destroy(e["graph"])
+            e = None
+        xy = batch_xy if batch_xy.dtype == torch.float32 else batch_xy.float()
+        small = [ops._f32c(t) for t in (batch_Rmats, batch_Tvecs, batch_inv_inmats, shape_code, appea_code)]
+        if self.audio_dim > 0:
+            small.append(ops._f32c(audiostyle))
+        if e is None:
+            if len(self._graphs) >= 8:  # a handful of call shapes per model in practice; do not grow without bound
+                old = self._graphs.pop(next(iter(self._graphs)))
+                ops.graph_destroy(old["graph"])
+            e = self._graphs[key] = self._record_graph(B, n_r, dev, sig, xy, small)
+        # packed weights follow the parameters' version counters; re-packed in place, so the recorded address stays valid
+        for fine in ((False, True) if self.hier_sampling else (False,)):
+            params, ws, bs = self._mlp_params(fine=fine)
+            assert self._packed(e["geom"], _lib.PRECISIONS[self.precision], params, ws, bs).data_ptr() == e["packed"][fine]
+        ops.stage_inputs([(xy, e["xy"])] + list(zip(small, e["small"])), view=xy)
+        ops.graph_launch(e["graph"])
+        imgs = e["imgs"] if self.graph_static_outputs else e["imgs"].clone()
+        return self._result(imgs, B, e["nb"])
+
+    def _record_graph(self, B, n_r, dev, sig, xy, small):
+        fs, C, P = self.featmap_size, self.featmap_nc, self.pred_img_size
+        prec = _lib.PRECISIONS[self.precision]
+        nb = (2 if self.hier_sampling else 1) * B
+        f32 = dict(dtype=torch.float32, device=dev)
+        e = {"sig": sig, "nb": nb, "xy": torch.empty(B, 2, n_r, **f32), "small": [torch.empty_like(t) for t in small],
+             "maps": torch.empty(nb + 1, fs, fs, C, **f32), "imgs": torch.empty(nb + 1, 3, P, P, **f32)}
+        geom = e["geom"] = self._geom(B, n_r, e["xy"])
+        bufs = {"render_ws": torch.empty(ops.render_workspace_bytes(geom, prec), dtype=torch.uint8, device=dev),
+                "nr_ws": torch.empty(ops.neural_render_workspace_bytes(self.neural_render._geom(nb + 1), nb + 1), dtype=torch.uint8, device=dev)}
+        packed = {}
+        if self.hier_sampling:
+            n_fine = self.num_sample_coarse + self.num_sample_fine
+            bufs["weight"] = torch.empty(B, n_r, self.num_sample_coarse, **f32)
+            bufs["planes"] = torch.empty(B, n_r, n_fine + 1, **f32)
+            gfine = self._geom(B, n_r, e["xy"], n_samples=n_fine, z_planes_given=1)
+            bufs["fine_ws"] = torch.empty(ops.render_workspace_bytes(gfine, prec), dtype=torch.uint8, device=dev)
+        for fine in ((False, True) if self.hier_sampling else (False,)):
+            params, ws, bs = self._mlp_params(fine=fine)
+            packed[fine] = self._packed(geom, prec, params, ws, bs).data_ptr()  # packs now, on the caller's stream
+        e["packed"], e["bufs"] = packed, bufs
+        R, T, Kinv, shape, appea = e["small"][:5]
+        audio = e["small"][5] if self.audio_dim > 0 else None
+        # record on a private stream (the legacy default stream cannot be captured); replays go to the caller's stream
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            ops.graph_begin(side)
+            try:
+                self._infer_launch(e["xy"], audio, shape, appea, R, T, Kinv, None, None, e["maps"], imgs=e["imgs"], bufs=bufs)
+            finally:
+                e["graph"] = ops.graph_end(side)
+        return e
+
+    def release_graphs(self):
+        """Destroy the recorded hipGraphs and their static buffers (they are re-recorded on demand)."""
+        for e in self._graphs.values():
+            ops.graph_destroy(e["graph"])
+        self._graphs.clear()
+
+    def __del__(self):
+        try:
+            self.release_graphs()
+        except Exception:
+            pass
 
     def _forward_train(self, batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand,
                        for_train=False, fine_u=None):

@@ -38,6 +38,7 @@ class _Workspace:
         self.buf = {}
 
     def get(self, key, nbytes, device):
+        assert device.type == "cuda", "libn3dt works on device memory only (no CPU fallback)"
         k = (key, device.index, torch.cuda.current_stream(device).cuda_stream)
         b = self.buf.get(k)
         if b is None or b.numel() < nbytes:
@@ -87,18 +88,23 @@ def render_params(to_rgb, psu1, psu2, feat):
     return p
 
 
-def pack_mlp(geom, precision, params, device):
+def pack_mlp(geom, precision, params, device, out=None):
     nbytes = lib().n3dt_mlp_packed_bytes(ctypes.byref(geom), precision)
     if nbytes == 0:
         raise _lib.N3dtError("n3dt_mlp_packed_bytes: " + lib().n3dt_last_error().decode())
-    packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    packed = out if out is not None and out.numel() >= nbytes else torch.empty(nbytes, dtype=torch.uint8, device=device)
     check(lib().n3dt_mlp_pack(ctypes.byref(geom), precision, ctypes.byref(params), _ptr(packed), _stream()), "n3dt_mlp_pack")
     return packed
 
 
+def render_workspace_bytes(geom, precision):
+    return _bytes_or_raise(lib().n3dt_render_workspace_bytes(ctypes.byref(geom), precision), "n3dt_render_workspace_bytes")
+
+
 def render_fwd(geom, precision, packed, params, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap,
-               want_depth=False, want_weight=False, want_merge=True, merge_out=None, want_fg=True):
-    """a1..a7 fused.  Returns dict(fg_feat [B,Nr,C]?, bg_alpha [B,Nr]?, depth?, weight?, merge_feat?)."""
+               want_depth=False, want_weight=False, want_merge=True, merge_out=None, want_fg=True, weight_out=None, ws=None):
+    """a1..a7 fused.  Returns dict(fg_feat [B,Nr,C]?, bg_alpha [B,Nr]?, depth?, weight?, merge_feat?).
+    With merge_out / weight_out / ws given (and want_fg, want_depth off) the call allocates nothing: hipGraph-capturable."""
     dev = xy.device
     B, Nr, Ns, C = geom.batch, geom.n_rays, geom.n_samples, geom.feat_nc
     assert want_fg or want_merge
@@ -106,14 +112,15 @@ def render_fwd(geom, precision, packed, params, xy, R, T, Kinv, shape, appea, au
         "fg_feat": torch.empty(B, Nr, C, dtype=torch.float32, device=dev) if want_fg else None,
         "bg_alpha": torch.empty(B, Nr, dtype=torch.float32, device=dev) if want_fg else None,
         "depth": torch.empty(B, Nr, dtype=torch.float32, device=dev) if want_depth else None,
-        "weight": torch.empty(B, Nr, Ns, dtype=torch.float32, device=dev) if want_weight else None,
+        "weight": (weight_out if weight_out is not None else torch.empty(B, Nr, Ns, dtype=torch.float32, device=dev))
+        if want_weight else None,
         "merge_feat": (merge_out if merge_out is not None else torch.empty(B, Nr, C, dtype=torch.float32, device=dev))
         if want_merge else None,
     }
-    ws_bytes = lib().n3dt_render_workspace_bytes(ctypes.byref(geom), precision)
-    if ws_bytes == 0:
-        raise _lib.N3dtError("n3dt_render_workspace_bytes: " + lib().n3dt_last_error().decode())
-    ws = WORKSPACE.get("render", ws_bytes, dev)
+    ws_bytes = render_workspace_bytes(geom, precision)
+    if ws is None:
+        ws = WORKSPACE.get("render", ws_bytes, dev)
+    assert ws.numel() >= ws_bytes
     rc = lib().n3dt_render_fwd(
         ctypes.byref(geom), precision, _ptr(packed), ctypes.byref(params), _ptr(xy), _ptr(R), _ptr(T), _ptr(Kinv),
         _ptr(shape), _ptr(appea), _ptr(audio), _ptr(t_rand), _ptr(bg_featmap) if want_merge else None,
@@ -123,10 +130,10 @@ def render_fwd(geom, precision, packed, params, xy, R, T, Kinv, shape, appea, au
     return out
 
 
-def fine_sample(geom, n_fine, weight, T, t_rand=None, u=None):
+def fine_sample(geom, n_fine, weight, T, t_rand=None, u=None, out=None):
     """Hierarchical sample planes (FineSample.forward): coarse weights [B,Nr,Nc] -> planes [B,Nr,Nc+n_fine+1]."""
     B, Nr, Nc = geom.batch, geom.n_rays, geom.n_samples
-    z = torch.empty(B, Nr, Nc + n_fine + 1, dtype=torch.float32, device=weight.device)
+    z = out if out is not None else torch.empty(B, Nr, Nc + n_fine + 1, dtype=torch.float32, device=weight.device)
     check(lib().n3dt_fine_sample(ctypes.byref(geom), int(n_fine), _ptr(weight), _ptr(T), _ptr(t_rand), _ptr(u), _ptr(z), _stream()),
           "n3dt_fine_sample")
     return z
@@ -196,15 +203,23 @@ def composite(rgb, density, z_dists, zvals):
     return feat, ba, dp, w
 
 
-def neural_render_fwd(geom, nb, rparams, featmap, precision=0):
-    """featmap [nb, fs, fs, C] (ray-major) -> img [nb, 3, P, P]"""
-    dev = featmap.device
-    P = geom.featmap_size << geom.n_blocks
-    img = torch.empty(nb, 3, P, P, dtype=torch.float32, device=dev)
+def neural_render_workspace_bytes(geom, nb):
     ws_bytes = lib().n3dt_neural_render_workspace_bytes(ctypes.byref(geom), nb)
     if ws_bytes == 0:
         raise _lib.N3dtError("n3dt_neural_render_workspace_bytes: unsupported geometry")
-    ws = WORKSPACE.get("nr", ws_bytes, dev)
+    return ws_bytes
+
+
+def neural_render_fwd(geom, nb, rparams, featmap, precision=0, img=None, ws=None):
+    """featmap [nb, fs, fs, C] (ray-major) -> img [nb, 3, P, P].  With img / ws given the call allocates nothing."""
+    dev = featmap.device
+    P = geom.featmap_size << geom.n_blocks
+    if img is None:
+        img = torch.empty(nb, 3, P, P, dtype=torch.float32, device=dev)
+    ws_bytes = neural_render_workspace_bytes(geom, nb)
+    if ws is None:
+        ws = WORKSPACE.get("nr", ws_bytes, dev)
+    assert ws.numel() >= ws_bytes
     check(lib().n3dt_neural_render_fwd(ctypes.byref(geom), nb, precision, ctypes.byref(rparams), _ptr(featmap), _ptr(img), _ptr(ws),
                                        ws_bytes, _stream()), "n3dt_neural_render_fwd")
     return img
@@ -216,6 +231,43 @@ def chw_to_hwc(src, C, n, dst=None):
         dst = torch.empty(n, C, dtype=torch.float32, device=src.device)
     check(lib().n3dt_chw_to_hwc(C, n, _ptr(src), _ptr(dst), _stream()), "n3dt_chw_to_hwc")
     return dst
+
+
+# ---- input staging + hipGraph replay -----------------------------------------------------------------
+def stage_inputs(pairs, view=None):
+    """One launch copying every (src, dst) pair of fp32 device tensors (dst contiguous).  `view`: the first pair's source is
+    read as a strided 3-D view -- pass the tensor itself (e.g. an expand()ed batch_xy), its sizes and strides are used."""
+    st = _lib.Stage()
+    assert 1 <= len(pairs) <= _lib.STAGE_MAX
+    for i, (src, dst) in enumerate(pairs):
+        assert src.is_cuda and dst.is_cuda and src.dtype == torch.float32 and dst.dtype == torch.float32 and dst.is_contiguous()
+        assert src.numel() == dst.numel() and (i == 0 and view is not None or src.is_contiguous())
+        st.src[i], st.dst[i], st.count[i] = src.data_ptr(), dst.data_ptr(), src.numel()
+    if view is not None:
+        assert view.dim() == 3
+        for d in range(3):
+            st.view_dims[d], st.view_strides[d] = view.shape[d], view.stride(d)
+    st.n = len(pairs)
+    check(lib().n3dt_stage_inputs(ctypes.byref(st), _stream()), "n3dt_stage_inputs")
+
+
+def graph_begin(stream):
+    check(lib().n3dt_graph_begin(ctypes.c_void_p(stream.cuda_stream)), "n3dt_graph_begin")
+
+
+def graph_end(stream):
+    h = ctypes.c_void_p()
+    check(lib().n3dt_graph_end(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(h)), "n3dt_graph_end")
+    return h
+
+
+def graph_launch(handle):
+    check(lib().n3dt_graph_launch(handle, _stream()), "n3dt_graph_launch")
+
+
+def graph_destroy(handle):
+    if handle:
+        lib().n3dt_graph_destroy(handle)
 
 
 # ---- training path -------------------------------------------------------------------------------

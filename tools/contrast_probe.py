@@ -1,0 +1,34 @@
+"""Error of every render precision on the high-contrast fixture (tests/golden/contrast.npz), stage by stage."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "nerf-3dtalker-code_amd"))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from conftest import load_golden, synthetic_case  # noqa: E402
+from n3dt import HeadNeRFNet  # noqa: E402
+
+g, m = load_golden(sys.argv[1] if len(sys.argv) > 1 else "contrast")
+opt, sd, inp = synthetic_case(m)
+dev = torch.device("cuda", 0)
+d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+step = int(g["ray_index_step"])
+for prec in ("fp32", "bf16", "fp16"):
+    net = HeadNeRFNet(opt, False, False, precision=prec).to(dev)
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        f = net.render_features(d["batch_xy"], d["audiostyle"], d["shape_code"], d["appea_code"], d["batch_Rmats"], d["batch_Tvecs"],
+                                d["batch_inv_inmats"], want_weight=True)
+        o = net("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+                d["batch_Tvecs"], d["batch_inv_inmats"])["coarse_dict"]
+    w = f["weight"].cpu().numpy()[:, None][:, :, ::step] if "weight" in g else None
+    img = o["merge_img"].cpu().numpy()
+    ref = g["merge_img_q16"].astype(np.float32) / 65535.0
+    e = np.abs(img - ref)
+    print("%s: weight max|err| %.3e  bg_alpha %.3e  fg_feat %.3e (scale %.1f)  merge_featmap-derived RGB: max %.3e  p99.9 %.3e  mean %.3e  frac>1e-3 %.2e" % (
+        prec, np.abs(w - g["weight"]).max() if w is not None else -1, np.abs(f["bg_alpha"].cpu().numpy()[:, None] - g["bg_alpha"]).max(),
+        np.abs(f["fg_feat"].permute(0, 2, 1).cpu().numpy()[:, :, ::step] - g["fg_feat"]).max(), np.abs(g["fg_feat"]).max(),
+        e.max(), np.quantile(e, 0.999), e.mean(), (e > 1e-3).mean()))
