@@ -63,6 +63,9 @@ typedef struct N3dtGeom {
      * `t_rand` in train mode, NetWorks/utils.py:118-145);  1: the `t_rand` argument of the render calls carries the
      * planes themselves, [B,N_r,N_s+1] ascending camera-relative z (the hierarchical pass, utils.py:173-208) */
     int32_t z_planes_given;
+    /* 0: `bg_featmap` arguments are the parameter as PyTorch holds it, [C][N_r] (neural_renderer.py:31-46) and the render call
+     * transposes it; 1: the caller passes it already ray-major [N_r][C] (e.g. cached per parameter version): no transposition */
+    int32_t bg_is_hwc;
 } N3dtGeom;
 
 /* The MLP's fp32 parameters as PyTorch owns them: weight[l] is [out_l, in_l] row-major
@@ -184,6 +187,19 @@ int n3dt_composite(int batch, int n_rays, int n_samples, int channels, const flo
 size_t n3dt_neural_render_workspace_bytes(const N3dtGeom* g, int nb);
 int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const float* featmap,
                            float* img, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The 16-bit modes re-lay the upsample blocks' fp32 weights into MFMA order at the start of every n3dt_neural_render_fwd
+ * (the renderer takes raw parameters, so it cannot know whether an optimizer touched them): three 6 us launches, 2.5 % of
+ * a one-head forward.  A caller that tracks its parameters (version counters) can split the two steps: the packed stream
+ * lives in the tail of the caller-owned workspace.
+ *   n3dt_neural_render_pack       re-packs the block weights into `workspace` (nothing else is touched);
+ *   n3dt_neural_render_fwd_reuse  = n3dt_neural_render_fwd minus the packing: valid when the same workspace was last packed
+ *                                   (by _pack or _fwd) for the same geometry, nb, precision and parameter VALUES.
+ * fp32 precision reads the raw parameters: _pack is a no-op and _fwd_reuse equals _fwd. */
+int n3dt_neural_render_pack(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int n3dt_neural_render_fwd_reuse(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const float* featmap,
+                                 float* img, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- training path (fwd -> loss -> backward) -----------------------------------
  * `precision` = N3DT_F32: exact fp32 (the mode the gradient-parity tests pin); N3DT_BF16: every matrix product

@@ -61,7 +61,7 @@ size_t n3dt_nr_train_ws_floats(const N3dtGeom*, int);
 void n3dt_launch_nr_train_fwd(const N3dtGeom*, int, const N3dtRenderParams*, const float*, float*, float*, float*, int, hipStream_t);
 void n3dt_launch_nr_bwd(const N3dtGeom*, int, const N3dtRenderParams*, const N3dtRenderGrads*, const float*, const float*, const float*,
                         float*, float*, int, hipStream_t);
-void n3dt_launch_neural_render(const N3dtGeom*, int, int, const N3dtRenderParams*, const float*, float*, float*, hipStream_t);
+void n3dt_launch_neural_render(const N3dtGeom*, int, int, const N3dtRenderParams*, const float*, float*, float*, int, hipStream_t);
 void n3dt_launch_stage(const N3dtStageCopy*, hipStream_t);
 }
 
@@ -228,8 +228,11 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
     }
     if (prof_lock.owns_lock()) prof_lock.unlock();
     const float* tail = (const float*)((const unsigned char*)packed_mlp + n3dt_packed_tail_offset(precision));
-    float* bghwc = (float*)(ws + c.bghwc);
-    if (merge_feat) n3dt_launch_chw_to_hwc(g->feat_nc, g->n_rays, bg_featmap, bghwc, s);  // [C][N_r] parameter -> [N_r][C]
+    const float* bghwc = bg_featmap;
+    if (merge_feat && !g->bg_is_hwc) {  // [C][N_r] parameter -> [N_r][C]
+        n3dt_launch_chw_to_hwc(g->feat_nc, g->n_rays, bg_featmap, (float*)(ws + c.bghwc), s);
+        bghwc = (const float*)(ws + c.bghwc);
+    }
     if (precision == N3DT_F32)
         n3dt_launch_ray_head(g, c.bpr, c.bs, part, wlocal, tail, bghwc, 1, fg_feat, bg_alpha, depth, weight, merge_feat, s);
     else
@@ -301,11 +304,11 @@ extern "C" size_t n3dt_neural_render_workspace_bytes(const N3dtGeom* g, int nb) 
     return n3dt_nr_workspace_floats(g, nb) * sizeof(float);
 }
 
-extern "C" int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const float* featmap,
-                                      float* img, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!g || !p || !featmap || !img || !workspace) return fail(N3DT_EINVAL, "n3dt_neural_render_fwd: NULL argument");
+static int neural_render_common(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const float* featmap, float* img,
+                                void* workspace, size_t workspace_bytes, int pack_mode, void* stream, const char* who) {
+    if (!g || !p || !workspace || (pack_mode != 2 && (!featmap || !img))) return fail(N3DT_EINVAL, "neural render: NULL argument");
     if (precision != N3DT_F32 && precision != N3DT_BF16 && precision != N3DT_F16) return fail(N3DT_EINVAL, "unknown precision");
-    if (nb < 1) return fail(N3DT_EINVAL, "n3dt_neural_render_fwd: nb < 1");
+    if (nb < 1) return fail(N3DT_EINVAL, "neural render: nb < 1");
     if (g->n_blocks < 1 || g->n_blocks > N3DT_MAX_BLOCKS) return fail(N3DT_EINVAL, "n_blocks must be in 1..8");
     if (g->feat_nc != 256) return fail(N3DT_EINVAL, "only featmap_nc == 256 is built");
     if (g->featmap_size < 2) return fail(N3DT_EINVAL, "featmap_size < 2 (reflect border needs 2 pixels)");
@@ -315,8 +318,23 @@ extern "C" int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, int precision, 
     for (int i = 0; i < g->n_blocks; ++i)
         if (!p->psu1_w[i] || !p->psu1_b[i] || !p->psu2_w[i] || !p->psu2_b[i] || !p->feat_w[i] || !p->feat_b[i])
             return fail(N3DT_EINVAL, "NULL neural-render block parameter");
-    n3dt_launch_neural_render(g, nb, precision, p, featmap, img, (float*)workspace, (hipStream_t)stream);
-    return check_hip("n3dt_neural_render_fwd");
+    n3dt_launch_neural_render(g, nb, precision, p, featmap, img, (float*)workspace, pack_mode, (hipStream_t)stream);
+    return check_hip(who);
+}
+
+extern "C" int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const float* featmap,
+                                      float* img, void* workspace, size_t workspace_bytes, void* stream) {
+    return neural_render_common(g, nb, precision, p, featmap, img, workspace, workspace_bytes, 0, stream, "n3dt_neural_render_fwd");
+}
+
+extern "C" int n3dt_neural_render_pack(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    return neural_render_common(g, nb, precision, p, nullptr, nullptr, workspace, workspace_bytes, 2, stream, "n3dt_neural_render_pack");
+}
+
+extern "C" int n3dt_neural_render_fwd_reuse(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const float* featmap,
+                                            float* img, void* workspace, size_t workspace_bytes, void* stream) {
+    return neural_render_common(g, nb, precision, p, featmap, img, workspace, workspace_bytes, 1, stream, "n3dt_neural_render_fwd_reuse");
 }
 
 extern "C" int n3dt_chw_to_hwc(int C, int n, const float* src, float* dst, void* stream) {

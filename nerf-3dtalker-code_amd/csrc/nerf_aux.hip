@@ -174,43 +174,62 @@ extern "C" void n3dt_launch_pack(const N3dtGeom* g, int precision, const N3dtMlp
 //   br1'[o] = br1[o] + Wr1[o, 384:].appea
 // grid (B, N3DT_NSTAGE), block 384
 // ---------------------------------------------------------------------------------------------
-__global__ void fold_latents_kernel(N3dtMlpParams p, int S, int A, int U, int merged, const float* __restrict__ shape,
-                                    const float* __restrict__ appea, const float* __restrict__ audio, float* __restrict__ fold) {
-    const int b = blockIdx.x, stage = blockIdx.y, o = threadIdx.x;
-    __shared__ float code[512];
+// One wavefront per output row: the lanes stride over the row's latent columns (coalesced 256-byte reads) and
+// reduce with a butterfly; the fp32 summation ORDER therefore differs from a serial loop (the products are the same) --
+// a few ulp on a bias, inside every mode's budget (the exact-fp32 gate is 1e-3 on RGB, measured 8e-6).
+// grid (B, N3DT_NSTAGE, FOLD_ROWGROUPS), block 256 (4 waves).  The first version ran one THREAD per row (a serial
+// 243-term loop over row-strided, uncoalesced loads): 23 us per call even at B = 1, now a launch latency.
+#define FOLD_ROWGROUPS 12
+__global__ __launch_bounds__(256) void fold_latents_kernel(N3dtMlpParams p, int S, int A, int U, int merged, const float* __restrict__ shape,
+                                                           const float* __restrict__ appea, const float* __restrict__ audio,
+                                                           float* __restrict__ fold) {
+    const int b = blockIdx.x, stage = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float code[512 + N3DT_HID];
     const int in0 = N3DT_PE_DIM + S + U, in5 = N3DT_PE_DIM + S + N3DT_HID, inr = N3DT_HID + A;
-    const int n_code = stage == 0 ? S + U : (stage == 5 ? S : (stage == 10 ? A : 0));
+    const N3dtStage st = n3dt_stage(stage);
+    float* out = fold + (size_t)b * N3DT_FOLD_STRIDE + n3dt_bias_offset(stage);
+    // the vector every row of this stage is dotted with, and where the row's matching columns start
+    int n_code = 0, col0 = 0, ld = 0;
+    if (stage == 0) { n_code = S + U; col0 = N3DT_PE_DIM; ld = in0; }
+    else if (stage == 5) { n_code = S; col0 = N3DT_PE_DIM; ld = in5; }
+    else if (stage == 10) {
+        // merged RGB_layer_0 -> RGB_layer_1 bias: br1' + Wr1[:, 0:384] . br0 -- one dot of the whole row with [br0 ; appea]
+        n_code = merged ? N3DT_HID + A : A;
+        col0 = merged ? 0 : N3DT_HID;
+        ld = inr;
+    }
     for (int i = threadIdx.x; i < n_code; i += blockDim.x) {
         float v;
-        if (stage == 10) v = appea[(size_t)b * A + i];
-        else v = i < S ? shape[(size_t)b * S + i] : audio[(size_t)b * U + (i - S)];
+        if (stage == 10) {
+            const int j = merged ? i - N3DT_HID : i;
+            v = j < 0 ? p.bias[9][i] : appea[(size_t)b * A + j];
+        } else {
+            v = i < S ? shape[(size_t)b * S + i] : audio[(size_t)b * U + (i - S)];
+        }
         code[i] = v;
     }
     __syncthreads();
-    const N3dtStage st = n3dt_stage(stage);
-    if (o >= st.N) return;
-    float* out = fold + (size_t)b * N3DT_FOLD_STRIDE + n3dt_bias_offset(stage);
-    if (stage == 8) {  // density: one real row
-        out[o] = o == 0 ? p.bias[8][0] : 0.0f;
-        return;
+    for (int o = blockIdx.z * 4 + wave; o < st.N; o += 4 * FOLD_ROWGROUPS) {
+        if (stage == 8) {  // density: one real row
+            if (lane == 0) out[o] = o == 0 ? p.bias[8][0] : 0.0f;
+            continue;
+        }
+        float acc = 0.0f;
+        if (n_code > 0) {
+            const float* w = p.weight[st.layer] + (size_t)o * ld + col0;
+            for (int i = lane; i < n_code; i += 64) acc = fmaf(w[i], code[i], acc);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        }
+        if (lane == 0) out[o] = p.bias[st.layer][o] + acc;
     }
-    float acc = p.bias[st.layer][o];
-    const float* w = nullptr;
-    if (stage == 0) w = p.weight[0] + (size_t)o * in0 + N3DT_PE_DIM;
-    else if (stage == 5) w = p.weight[5] + (size_t)o * in5 + N3DT_PE_DIM;
-    else if (stage == 10) w = p.weight[10] + (size_t)o * inr + N3DT_HID;
-    for (int i = 0; i < n_code; ++i) acc = fmaf(w[i], code[i], acc);
-    if (stage == 10 && merged) {  // bias of the merged RGB_layer_0 -> RGB_layer_1 matrix: br1' + Wr1[:, 0:384] . br0
-        const float* w1 = p.weight[10] + (size_t)o * inr;
-        for (int j = 0; j < N3DT_HID; ++j) acc = fmaf(w1[j], p.bias[9][j], acc);
-    }
-    out[o] = acc;
 }
 
 extern "C" void n3dt_launch_fold(const N3dtGeom* g, const N3dtMlpParams* p, const float* shape, const float* appea,
                                  const float* audio, float* fold, int merged_rgb, hipStream_t stream) {
-    hipLaunchKernelGGL(fold_latents_kernel, dim3(g->batch, N3DT_NSTAGE), dim3(384), 0, stream, *p, g->shape_dim, g->appea_dim,
-                       g->audio_dim, merged_rgb, shape, appea, audio, fold);
+    hipLaunchKernelGGL(fold_latents_kernel, dim3(g->batch, N3DT_NSTAGE, FOLD_ROWGROUPS), dim3(256), 0, stream, *p, g->shape_dim,
+                       g->appea_dim, g->audio_dim, merged_rgb, shape, appea, audio, fold);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -211,13 +211,16 @@ static NrCarve nr_carve(const N3dtGeom* g, int nb) {
 
 extern "C" size_t n3dt_nr_workspace_floats(const N3dtGeom* g, int nb) { return nr_carve(g, nb).total; }
 
+// pack_mode: 0 = pack the fused blocks' weights into the workspace tail and render; 1 = render with the stream a previous call
+// left there; 2 = pack only.  The fp32 path reads the raw parameters (nothing to pack).
 extern "C" void n3dt_launch_neural_render(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p,
-                                          const float* featmap, float* img, float* ws, hipStream_t s) {
+                                          const float* featmap, float* img, float* ws, int pack_mode, hipStream_t s) {
     const NrCarve cv = nr_carve(g, nb);
     if (precision != N3DT_F32) {  // 16-bit activations, blur commuted behind feat_layers (neural_render_x16.inc)
-        n3dt_launch_neural_render_x16(g, nb, precision, p, featmap, img, ws, cv.total, s);
+        n3dt_launch_neural_render_x16(g, nb, precision, p, featmap, img, ws, cv.total, pack_mode, s);
         return;
     }
+    if (pack_mode == 2) return;
     float* t1 = ws;
     float* ps = t1 + cv.t1;
     float* bl = ps + cv.ps;

@@ -25,7 +25,7 @@ class Geom(ctypes.Structure):
         ("appea_dim", ctypes.c_int32), ("audio_dim", ctypes.c_int32), ("featmap_size", ctypes.c_int32),
         ("n_blocks", ctypes.c_int32), ("world_z1", ctypes.c_float), ("world_z2", ctypes.c_float),
         ("xy_stride_b", ctypes.c_int64), ("xy_stride_c", ctypes.c_int64), ("xy_stride_r", ctypes.c_int64),
-        ("z_planes_given", ctypes.c_int32),
+        ("z_planes_given", ctypes.c_int32), ("bg_is_hwc", ctypes.c_int32),
     ]
 
 
@@ -50,7 +50,7 @@ EXPORTS = [
     "n3dt_neural_render_train_saved_bytes", "n3dt_neural_render_train_workspace_bytes",
     "n3dt_neural_render_train_fwd", "n3dt_neural_render_bwd", "n3dt_loss_fwd", "n3dt_loss_bwd", "n3dt_fine_sample",
     "n3dt_img_to_uint8", "n3dt_sample_points", "n3dt_embed", "n3dt_mlp_points_workspace_bytes", "n3dt_mlp_points", "n3dt_composite",
-    "n3dt_stage_inputs", "n3dt_graph_begin", "n3dt_graph_end", "n3dt_graph_launch", "n3dt_graph_destroy",
+    "n3dt_neural_render_pack", "n3dt_neural_render_fwd_reuse", "n3dt_stage_inputs", "n3dt_graph_begin", "n3dt_graph_end", "n3dt_graph_launch", "n3dt_graph_destroy",
 ]
 
 STAGE_MAX = 12
@@ -91,6 +91,10 @@ def lib():
     L.n3dt_neural_render_workspace_bytes.argtypes = [ctypes.POINTER(Geom), ci]
     L.n3dt_neural_render_fwd.restype = ci
     L.n3dt_neural_render_fwd.argtypes = [ctypes.POINTER(Geom), ci, ci, ctypes.POINTER(RenderParams), vp, vp, vp, sz, vp]
+    L.n3dt_neural_render_fwd_reuse.restype = ci
+    L.n3dt_neural_render_fwd_reuse.argtypes = [ctypes.POINTER(Geom), ci, ci, ctypes.POINTER(RenderParams), vp, vp, vp, sz, vp]
+    L.n3dt_neural_render_pack.restype = ci
+    L.n3dt_neural_render_pack.argtypes = [ctypes.POINTER(Geom), ci, ci, ctypes.POINTER(RenderParams), vp, sz, vp]
     L.n3dt_chw_to_hwc.restype = ci
     L.n3dt_chw_to_hwc.argtypes = [ci, ci, vp, vp, vp]
     gp, mp, rp = ctypes.POINTER(Geom), ctypes.POINTER(MlpParams), ctypes.POINTER(RenderParams)

@@ -105,6 +105,8 @@ class NeuralRenderer(nn.Module):
         super().__init__()
         assert out_dim == 3 and final_actvn and min_feat == 32
         self.bg_type = bg_type
+        self._packed_sig = {}  # workspace address -> (parameter versions, nb, precision) its packed block weights were made from
+        self._own_ws = {}
         self.train_precision = "fp32"  # "bf16": matrix products of the differentiable path on bf16 MFMA
         self.featmap_size = featmap_size
         self.n_feat = feat_nc
@@ -157,11 +159,38 @@ class NeuralRenderer(nn.Module):
             flat += [m.weight, m.bias]
         return _NeuralRenderFn.apply(self, featmap_hwc, *flat)
 
+    def _param_sig(self):
+        return tuple((p.data_ptr(), p._version) for m in self._flat_modules() for p in (m.weight, m.bias))
+
+    def ensure_packed(self, nb, precision, ws):
+        """16-bit modes: the blocks' weights in MFMA order live in the tail of the workspace `ws`; (re-)pack them there
+        when a parameter's version counter moved since this workspace was last packed.  Returns the parameter struct."""
+        rp = self._rparams()
+        prec = _lib.PRECISIONS[precision]
+        if prec != _lib.F32:
+            sig = (self._param_sig(), nb, prec)
+            if self._packed_sig.get(ws.data_ptr()) != sig:
+                ops.neural_render_pack(self._geom(nb), nb, rp, prec, ws)
+                self._packed_sig[ws.data_ptr()] = sig
+        return rp
+
+    def invalidate_packed(self):
+        self._packed_sig.clear()
+
     def render_hwc(self, featmap_hwc, precision="fp32", img=None, ws=None):
-        """[nb, fs, fs, C] ray-major feature maps -> [nb, 3, P, P] (img / ws: caller-owned buffers, nothing is allocated)"""
+        """[nb, fs, fs, C] ray-major feature maps -> [nb, 3, P, P].  img / ws: caller-owned buffers (nothing is allocated
+        then); without `ws` the module keeps one workspace per (nb, device, stream), which also holds its packed weights."""
         nb = featmap_hwc.shape[0]
         assert featmap_hwc.is_contiguous()
-        return ops.neural_render_fwd(self._geom(nb), nb, self._rparams(), featmap_hwc, _lib.PRECISIONS[precision], img=img, ws=ws)
+        geom = self._geom(nb)
+        if ws is None:
+            dev = featmap_hwc.device
+            key = (nb, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+            ws = self._own_ws.get(key)
+            if ws is None:
+                ws = self._own_ws[key] = torch.empty(ops.neural_render_workspace_bytes(geom, nb), dtype=torch.uint8, device=dev)
+        rp = self.ensure_packed(nb, precision, ws)
+        return ops.neural_render_fwd(geom, nb, rp, featmap_hwc, _lib.PRECISIONS[precision], img=img, ws=ws, reuse_packed=True)
 
     def forward(self, x):
         """x: [nb, C, fs, fs] like the reference module."""
@@ -331,8 +360,22 @@ class HeadNeRFNet(nn.Module):
         self.use_graph = (os.environ.get("N3DT_GRAPH", "1") != "0") if use_graph is None else bool(use_graph)
         self.graph_static_outputs = graph_static_outputs
         self._graphs = {}
+        self._bg_cache = None
         # a (strict or not) load_state_dict replaces every weight: drop the packed copies
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_packed())
+
+    def _bg_hwc(self):
+        """neural_render.bg_featmap [1,C,fs,fs] as the kernels read it, ray-major [fs*fs, C]: transposed once per parameter
+        version into a buffer whose address never changes (recorded graphs read it)."""
+        bg = self.neural_render.bg_featmap
+        ver = (bg.data_ptr(), bg._version)
+        c = self._bg_cache
+        if c is None or c[0] != ver:
+            fs, C = self.featmap_size, self.featmap_nc
+            dst = c[1] if c is not None and c[1].device == bg.device else torch.empty(fs * fs, C, dtype=torch.float32, device=bg.device)
+            ops.chw_to_hwc(bg.detach().view(C, fs * fs), C, fs * fs, dst)
+            self._bg_cache = c = (ver, dst)
+        return c[1]
 
     def invalidate_packed(self):
         """Forget the packed (MFMA-ordered, 16-bit) copies of the MLP weights.  They are rebuilt on the next call.
@@ -341,6 +384,10 @@ class HeadNeRFNet(nn.Module):
         `model.state_dict()[k].data.copy_(v)`, talker_trainer.py:557-567) do NOT move them -- call this after such a
         write, or use n3dt.checkpoint.load_ckpt, which does."""
         self._pack_cache.clear()
+        self._bg_cache = None
+        self.neural_render.invalidate_packed()
+        for e in self._graphs.values():
+            e["bg_ver"] = None
 
     def _build_info(self, opt):
         self.num_sample_coarse = opt.num_sample_coarse
@@ -376,10 +423,10 @@ class HeadNeRFNet(nn.Module):
     def _shape_dim(self):
         return self.base_shape_code_dims + (self.eye_gaze_dim if self.include_gaze else 0)
 
-    def _geom(self, batch, n_rays, xy, n_samples=None, z_planes_given=0):
+    def _geom(self, batch, n_rays, xy, n_samples=None, z_planes_given=0, bg_is_hwc=0):
         return ops.make_geom(batch, n_rays, n_samples or self.num_sample_coarse, self.mlp_h_channel, self.featmap_nc,
                              self._shape_dim(), self.base_appea_code_dims, self.audio_dim, self.featmap_size,
-                             self.neural_render.n_blocks, self.opt.world_z1, self.opt.world_z2, xy.stride(), z_planes_given)
+                             self.neural_render.n_blocks, self.opt.world_z1, self.opt.world_z2, xy.stride(), z_planes_given, bg_is_hwc)
 
     def _mlp_params(self, fine=False):
         layers = (self.fine_fg_CD_predictor if fine else self.fg_CD_predictor).layers()
@@ -410,16 +457,16 @@ class HeadNeRFNet(nn.Module):
         if z_planes is not None:
             assert self.hier_sampling and t_rand is None
             t_rand = z_planes
-            geom = self._geom(B, n_r, xy, n_samples=z_planes.shape[-1] - 1, z_planes_given=1)
+            geom = self._geom(B, n_r, xy, n_samples=z_planes.shape[-1] - 1, z_planes_given=1, bg_is_hwc=1)
         else:
-            geom = self._geom(B, n_r, xy)
+            geom = self._geom(B, n_r, xy, bg_is_hwc=1)
         params, ws, bs = self._mlp_params(fine=z_planes is not None)
         packed = self._packed(geom, prec, params, ws, bs)
         audio = ops._f32c(audiostyle) if self.audio_dim > 0 else None
         out = ops.render_fwd(geom, prec, packed, params, xy, ops._f32c(batch_Rmats), ops._f32c(batch_Tvecs).view(B, 3),
                              ops._f32c(batch_inv_inmats), ops._f32c(shape_code), ops._f32c(appea_code), audio,
                              None if t_rand is None else ops._f32c(t_rand),
-                             self.neural_render.bg_featmap.detach().view(self.featmap_nc, -1) if want_merge else None,
+                             self._bg_hwc() if want_merge else None,  # ray-major, cached per parameter version
                              want_depth=want_depth, want_weight=want_weight, want_merge=want_merge, merge_out=merge_out,
                              want_fg=want_fg, weight_out=weight_out, ws=workspace)
         return out
@@ -484,7 +531,8 @@ class HeadNeRFNet(nn.Module):
             self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
                                  z_planes=planes, want_merge=True, want_fg=False,
                                  merge_out=maps[batch_size:nb].view(batch_size, fs * fs, C), workspace=bufs.get("fine_ws"))
-        ops.chw_to_hwc(self.neural_render.bg_featmap.detach().view(C, fs * fs), C, fs * fs, maps[nb].view(fs * fs, C))
+        if "nr_ws" not in bufs:  # (a recorded graph keeps the background map in its static batch: see _forward_graph)
+            maps[nb].view(fs * fs, C).copy_(self._bg_hwc())
         return self.neural_render.render_hwc(maps, self.precision, img=imgs, ws=bufs.get("nr_ws"))
 
     # ---- hipGraph replay of the inference forward ---------------------------------------------------------------
@@ -520,10 +568,22 @@ class HeadNeRFNet(nn.Module):
         for fine in ((False, True) if self.hier_sampling else (False,)):
             params, ws, bs = self._mlp_params(fine=fine)
             assert self._packed(e["geom"], _lib.PRECISIONS[self.precision], params, ws, bs).data_ptr() == e["packed"][fine]
+        self._refresh_graph_constants(e)
         ops.stage_inputs([(xy, e["xy"])] + list(zip(small, e["small"])), view=xy)
         ops.graph_launch(e["graph"])
         imgs = e["imgs"] if self.graph_static_outputs else e["imgs"].clone()
         return self._result(imgs, B, e["nb"])
+
+    def _refresh_graph_constants(self, e):
+        """What a replay reads but does not compute: the background map's slot of the renderer batch and the renderer's packed
+        block weights, refreshed (on the caller's stream, ahead of the replay) when their parameters' versions moved."""
+        bg = self.neural_render.bg_featmap
+        ver = (bg.data_ptr(), bg._version)
+        if e.get("bg_ver") != ver:
+            fs, C = self.featmap_size, self.featmap_nc
+            e["maps"][e["nb"]].view(fs * fs, C).copy_(self._bg_hwc())
+            e["bg_ver"] = ver
+        self.neural_render.ensure_packed(e["nb"] + 1, self.precision, e["bufs"]["nr_ws"])
 
     def _record_graph(self, B, n_r, dev, sig, xy, small):
         fs, C, P = self.featmap_size, self.featmap_nc, self.pred_img_size
@@ -546,6 +606,8 @@ class HeadNeRFNet(nn.Module):
             params, ws, bs = self._mlp_params(fine=fine)
             packed[fine] = self._packed(geom, prec, params, ws, bs).data_ptr()  # packs now, on the caller's stream
         e["packed"], e["bufs"] = packed, bufs
+        self._bg_hwc()
+        self._refresh_graph_constants(e)
         R, T, Kinv, shape, appea = e["small"][:5]
         audio = e["small"][5] if self.audio_dim > 0 else None
         # record on a private stream (the legacy default stream cannot be captured); replays go to the caller's stream

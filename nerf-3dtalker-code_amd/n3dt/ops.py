@@ -51,9 +51,10 @@ WORKSPACE = _Workspace()
 
 
 def make_geom(batch, n_rays, n_samples, hidden, feat_nc, shape_dim, appea_dim, audio_dim, featmap_size, n_blocks,
-              world_z1, world_z2, xy_strides=(0, 0, 0), z_planes_given=0):
+              world_z1, world_z2, xy_strides=(0, 0, 0), z_planes_given=0, bg_is_hwc=0):
     g = Geom()
     g.z_planes_given = int(z_planes_given)
+    g.bg_is_hwc = int(bg_is_hwc)
     g.batch, g.n_rays, g.n_samples = int(batch), int(n_rays), int(n_samples)
     g.hidden, g.feat_nc = int(hidden), int(feat_nc)
     g.shape_dim, g.appea_dim, g.audio_dim = int(shape_dim), int(appea_dim), int(audio_dim)
@@ -210,8 +211,15 @@ def neural_render_workspace_bytes(geom, nb):
     return ws_bytes
 
 
-def neural_render_fwd(geom, nb, rparams, featmap, precision=0, img=None, ws=None):
-    """featmap [nb, fs, fs, C] (ray-major) -> img [nb, 3, P, P].  With img / ws given the call allocates nothing."""
+def neural_render_pack(geom, nb, rparams, precision, ws):
+    """Re-pack the upsample blocks' weights into the tail of `ws` (16-bit modes; a no-op in fp32)."""
+    check(lib().n3dt_neural_render_pack(ctypes.byref(geom), nb, precision, ctypes.byref(rparams), _ptr(ws), ws.numel(), _stream()),
+          "n3dt_neural_render_pack")
+
+
+def neural_render_fwd(geom, nb, rparams, featmap, precision=0, img=None, ws=None, reuse_packed=False):
+    """featmap [nb, fs, fs, C] (ray-major) -> img [nb, 3, P, P].  With img / ws given the call allocates nothing.
+    reuse_packed: `ws` was last packed (neural_render_pack / a previous call) for these parameter values: skip the packing."""
     dev = featmap.device
     P = geom.featmap_size << geom.n_blocks
     if img is None:
@@ -220,8 +228,9 @@ def neural_render_fwd(geom, nb, rparams, featmap, precision=0, img=None, ws=None
     if ws is None:
         ws = WORKSPACE.get("nr", ws_bytes, dev)
     assert ws.numel() >= ws_bytes
-    check(lib().n3dt_neural_render_fwd(ctypes.byref(geom), nb, precision, ctypes.byref(rparams), _ptr(featmap), _ptr(img), _ptr(ws),
-                                       ws_bytes, _stream()), "n3dt_neural_render_fwd")
+    fn = lib().n3dt_neural_render_fwd_reuse if reuse_packed else lib().n3dt_neural_render_fwd
+    check(fn(ctypes.byref(geom), nb, precision, ctypes.byref(rparams), _ptr(featmap), _ptr(img), _ptr(ws), ws_bytes, _stream()),
+          "n3dt_neural_render_fwd")
     return img
 
 
