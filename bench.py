@@ -35,7 +35,7 @@ sys.path.insert(0, REPO)
 
 FLOP_PER_POINT = 2702592          # latent-folded MLP query, SURVEY 8(d)
 FLOP_PER_POINT_EXECUTED = 2375 * 32768 // 32  # MFMA work actually issued per point: 2280 weight pieces + 95 bias MFMAs per 32 samples (RGB_layer_0 merged into RGB_layer_1, RGB_layer_2 per ray)
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0}  # dense, MI355X_MICROARCH.md
 GEOMETRY = {"cfg2": (64, 64, 512), "cfg4": (32, 64, 256), "cfg5": (32, 96, 1024)}  # featmap_size, samples, image
 
 
@@ -302,6 +302,8 @@ def extras(ctx):
     rec("cfg2-N_bf16_b1", "bf16", lambda k, w: run_render(ctx, "cfg2", "bf16", 1, "N", k, w, prof=False), 4, 2)
     rec("cfg2-R_fp32_b4", "fp32 parity mode", lambda k, w: run_render(ctx, "cfg2", "fp32", 4, "R", k, w, prof=False), 4, 2)
     rec("cfg2-R_bf16_b1", "bf16, one head per step (latency)", lambda k, w: run_render(ctx, "cfg2", "bf16", 1, "R", k, w, prof=False), 20, 5)
+    rec("cfg2-R_bf16x3_b16", "bf16 MFMA, operands split hi+lo (3 products): the parity-grade MFMA mode; roofline_frac is algorithmic",
+        lambda k, w: run_render(ctx, "cfg2", "bf16x3", 16, "R", k, w, prof=False), 6, 2)
     rec("cfg2-R_fp16_b16", "fp16", lambda k, w: run_render(ctx, "cfg2", "fp16", 16, "R", k, w, prof=False), 10, 3)
     rec("cfg3_train_bf16_b2", "fused bf16 training path", lambda k, w: run_train(ctx, "cfg2", "bf16", 2, k, w), 5, 2)
     rec("cfg3_train_fp32_b2", "exact fp32 training path", lambda k, w: run_train(ctx, "cfg2", "fp32", 2, k, w), 4, 2)
@@ -317,7 +319,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "bf16x3"])
     ap.add_argument("--rays", default="R", choices=["R", "N"],
                     help="R: rays = featmap_size^2 (reference-faithful); N: 512^2 rays, feature stage only")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
@@ -396,7 +398,7 @@ def main():
                 "ranks_seen_by_backend": seen,
             },
             "roofline": {
-                "kernel": "nerf_fwd_x16_kernel" if args.precision != "fp32" else "nerf_fwd_f32_kernel",
+                "kernel": {"fp32": "nerf_fwd_f32_kernel", "bf16x3": "nerf_fwd_x16s_kernel"}.get(args.precision, "nerf_fwd_x16_kernel"),
                 "bound": "mfma", "achieved": r["achieved"], "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s", "frac": r["frac"],
                 "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": r["kern_ms"], "points_per_launch": r["points"],

@@ -32,6 +32,11 @@ extern "C" {
 #define N3DT_F32 0  /* v_mfma_f32_16x16x4_f32, exact fp32: the <=1e-3 RGB parity mode */
 #define N3DT_BF16 1 /* v_mfma_f32_32x32x16_bf16, fp32 accumulate: the roofline mode  */
 #define N3DT_F16 2  /* v_mfma_f32_32x32x16_f16,  fp32 accumulate                      */
+/* bf16 MFMA with every operand split hi + lo (x = bf16(x) + bf16(x - bf16(x)), three products per product, ~16 mantissa bits):
+ * the parity-grade mode on the matrix pipe -- holds the 1e-3 RGB gate on sharp networks where single bf16 / fp16 operands do
+ * not, at a third of the bf16 rate.  Render calls only (n3dt_mlp_pack, n3dt_render_fwd,
+ * n3dt_neural_render_fwd, where the 2-D renderer then runs its fp16 path); the training entry points take F32 or BF16. */
+#define N3DT_BF16X3 3
 
 #define N3DT_OK 0
 #define N3DT_EINVAL (-1)    /* bad geometry / null pointer / unsupported size */

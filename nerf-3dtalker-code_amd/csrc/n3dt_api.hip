@@ -33,6 +33,8 @@ void n3dt_launch_nerf_fwd_f32(const N3dtGeom*, const N3dtMlpParams*, const void*
                               const float*, const float*, const float*, float*, float*, hipStream_t);
 void n3dt_launch_nerf_fwd_x16(const N3dtGeom*, int, const void*, const float*, const float*, const float*, const float*,
                               const float*, const float*, float*, float*, hipStream_t);
+void n3dt_launch_nerf_fwd_x16s(const N3dtGeom*, const void*, const float*, const float*, const float*, const float*, const float*,
+                               const float*, float*, float*, hipStream_t);
 void n3dt_launch_nerf_fwd_x16b(const N3dtGeom*, int, const void*, const float*, const float*, const float*, const float*,
                                const float*, const float*, float*, float*, hipStream_t);
 size_t n3dt_nr_workspace_floats(const N3dtGeom*, int);
@@ -83,7 +85,8 @@ static int check_hip(const char* where) {
 
 static int check_geom(const N3dtGeom* g, int precision) {
     if (!g) return fail(N3DT_EINVAL, "geometry is NULL");
-    if (precision != N3DT_F32 && precision != N3DT_BF16 && precision != N3DT_F16) return fail(N3DT_EINVAL, "unknown precision");
+    if (precision != N3DT_F32 && precision != N3DT_BF16 && precision != N3DT_F16 && precision != N3DT_BF16X3)
+        return fail(N3DT_EINVAL, "unknown precision");
     if (g->batch < 1 || g->n_rays < 1 || g->n_samples < 1) return fail(N3DT_EINVAL, "batch, n_rays and n_samples must be >= 1");
     if (g->n_samples > 1024) return fail(N3DT_EINVAL, "n_samples > 1024 is not supported");
     if (g->hidden != 384) return fail(N3DT_EINVAL, "only mlp_hidden_nchannels == 384 is built");
@@ -217,6 +220,8 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_n], s);
     if (precision == N3DT_F32)
         n3dt_launch_nerf_fwd_f32(g, p, packed_mlp, fold, xy, R, T, Kinv, t_rand, part, weight ? wlocal : nullptr, s);
+    else if (precision == N3DT_BF16X3)
+        n3dt_launch_nerf_fwd_x16s(g, packed_mlp, fold, xy, R, T, Kinv, t_rand, part, weight ? wlocal : nullptr, s);
     else if (x16_tiling() == 3)
         n3dt_launch_nerf_fwd_x16b(g, precision, (const unsigned char*)packed_mlp + n3dt_packed_region_b_offset(precision), fold, xy, R, T,
                                   Kinv, t_rand, part, weight ? wlocal : nullptr, s);
@@ -307,6 +312,9 @@ extern "C" size_t n3dt_neural_render_workspace_bytes(const N3dtGeom* g, int nb) 
 static int neural_render_common(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const float* featmap, float* img,
                                 void* workspace, size_t workspace_bytes, int pack_mode, void* stream, const char* who) {
     if (!g || !p || !workspace || (pack_mode != 2 && (!featmap || !img))) return fail(N3DT_EINVAL, "neural render: NULL argument");
+    // the split-precision mode renders the 2-D stage on its fp16 path: 2.3e-4 on RGB where bf16 maps reach 1.6e-3 (fixture
+    // `contrast`, features O(10)), inside the mode's 1e-3 budget without splitting the renderer's products as well
+    if (precision == N3DT_BF16X3) precision = N3DT_F16;
     if (precision != N3DT_F32 && precision != N3DT_BF16 && precision != N3DT_F16) return fail(N3DT_EINVAL, "unknown precision");
     if (nb < 1) return fail(N3DT_EINVAL, "neural render: nb < 1");
     if (g->n_blocks < 1 || g->n_blocks > N3DT_MAX_BLOCKS) return fail(N3DT_EINVAL, "n_blocks must be in 1..8");

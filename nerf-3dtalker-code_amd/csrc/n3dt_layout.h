@@ -60,15 +60,17 @@ __host__ __device__ inline size_t n3dt_packed_elem_bytes(int precision) { return
 
 // The 16-bit precisions carry the matrices twice: region A in the fragment order of the 32x32x16 MFMA tiling
 // (nerf_fwd_x16.hip, the training kernels), region B in that of the 16x16x32 tiling (nerf_fwd_x16b.hip).
+// The split-precision mode (precision 3, nerf_fwd_x16s.hip) carries ONE region in the 32x32x16 order with every 1 KiB piece
+// twice: piece 2P = bf16(W), piece 2P + 1 = bf16(W - bf16(W)).
 __host__ __device__ inline size_t n3dt_packed_region_bytes(int precision) {
-    size_t b = n3dt_packed_matrix_elems() * n3dt_packed_elem_bytes(precision);
+    size_t b = n3dt_packed_matrix_elems() * n3dt_packed_elem_bytes(precision) * (precision == 3 ? 2 : 1);
     return (b + 255) & ~(size_t)255;
 }
 __host__ __device__ inline size_t n3dt_packed_region_b_offset(int precision) { return n3dt_packed_region_bytes(precision); }
 
 // byte offset of the fp32 tail (256-byte aligned)
 __host__ __device__ inline size_t n3dt_packed_tail_offset(int precision) {
-    return (precision == 0 ? 1 : 2) * n3dt_packed_region_bytes(precision);
+    return ((precision == 0 || precision == 3) ? 1 : 2) * n3dt_packed_region_bytes(precision);
 }
 
 // per-frame bias table in the workspace, [B][N3DT_FOLD_STRIDE], stage order:

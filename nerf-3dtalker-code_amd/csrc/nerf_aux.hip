@@ -120,6 +120,13 @@ __global__ void pack_mlp_kernel(N3dtMlpParams p, int precision, int order16, int
             reinterpret_cast<float*>(out)[base + e] = v;
         } else if (precision == N3DT_BF16) {
             reinterpret_cast<unsigned short*>(out)[base + e] = f32_to_bf16_rne(v);
+        } else if (precision == N3DT_BF16X3) {
+            // piece (e >> 9) of the one-product order becomes pieces 2P (hi) and 2P + 1 (lo); 512 elements per piece
+            const size_t P = (base + e) >> 9, in = (base + e) & 511;
+            const __bf16 hi = (__bf16)v;
+            const __bf16 lo = (__bf16)(v - (float)hi);
+            reinterpret_cast<unsigned short*>(out)[(2 * P) * 512 + in] = __builtin_bit_cast(unsigned short, hi);
+            reinterpret_cast<unsigned short*>(out)[(2 * P + 1) * 512 + in] = __builtin_bit_cast(unsigned short, lo);
         } else {
             _Float16 hv = (_Float16)v;
             reinterpret_cast<unsigned short*>(out)[base + e] = __builtin_bit_cast(unsigned short, hv);
@@ -158,7 +165,7 @@ extern "C" void n3dt_launch_pack(const N3dtGeom* g, int precision, const N3dtMlp
         n3dt_launch_small_gemm(192, 384, 384, p->weight[10], 384 + g->appea_dim, 1, p->weight[9], 1, 384, wm, 384, 0, stream);
     hipLaunchKernelGGL(pack_mlp_kernel, dim3(64, N3DT_NSTAGE), dim3(256), 0, stream, *p, precision, 0, g->shape_dim, g->appea_dim,
                        g->audio_dim, wm, reinterpret_cast<unsigned char*>(packed));
-    if (precision != N3DT_F32)
+    if (precision == N3DT_BF16 || precision == N3DT_F16)
         hipLaunchKernelGGL(pack_mlp_kernel, dim3(64, N3DT_NSTAGE), dim3(256), 0, stream, *p, precision, 1, g->shape_dim, g->appea_dim,
                            g->audio_dim, wm, reinterpret_cast<unsigned char*>(packed) + n3dt_packed_region_b_offset(precision));
     const int n = N3DT_G * N3DT_C + N3DT_C + 12 * 8 * 2 * 64;

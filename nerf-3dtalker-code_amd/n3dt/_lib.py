@@ -10,8 +10,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("N3DT_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libn3dt.so")
 
-F32, BF16, F16 = 0, 1, 2
-PRECISIONS = {"fp32": F32, "f32": F32, "bf16": BF16, "fp16": F16, "f16": F16}
+F32, BF16, F16, BF16X3 = 0, 1, 2, 3
+PRECISIONS = {"fp32": F32, "f32": F32, "bf16": BF16, "fp16": F16, "f16": F16, "bf16x3": BF16X3}
 MLP_LAYERS = 12
 MAX_BLOCKS = 8
 

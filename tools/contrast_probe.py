@@ -16,7 +16,7 @@ opt, sd, inp = synthetic_case(m)
 dev = torch.device("cuda", 0)
 d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
 step = int(g["ray_index_step"])
-for prec in ("fp32", "bf16", "fp16"):
+for prec in ("fp32", "bf16", "fp16", "bf16x3"):
     net = HeadNeRFNet(opt, False, False, precision=prec).to(dev)
     net.load_state_dict(sd)
     with torch.no_grad():
