@@ -35,6 +35,18 @@ sys.path.insert(0, REPO)
 
 FLOP_PER_POINT = 2702592          # latent-folded MLP query, SURVEY 8(d)
 FLOP_PER_POINT_EXECUTED = 2375 * 32768 // 32  # MFMA work actually issued per point: 2280 weight pieces + 95 bias MFMAs per 32 samples (RGB_layer_0 merged into RGB_layer_1, RGB_layer_2 per ray)
+
+
+def flop_per_point_executed(precision):
+    """MFMA work actually issued per sample point.  16-bit modes: 2280 weight pieces + 95 bias MFMAs of 32x32x16 per 32 samples;
+    the split mode issues three MFMAs per weight piece pair; the fp32 kernel issues the reference's dense (un-merged) layers."""
+    if precision == "bf16x3":
+        return (3 * 2280 + 95) * 32768 // 32
+    if precision == "fp32":
+        return FLOP_PER_POINT
+    return FLOP_PER_POINT_EXECUTED
+
+
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0}  # dense, MI355X_MICROARCH.md
 GEOMETRY = {"cfg2": (64, 64, 512), "cfg4": (32, 64, 256), "cfg5": (32, 96, 1024)}  # featmap_size, samples, image
 
@@ -180,7 +192,8 @@ def run_render(ctx, config, precision, batch, rays, steps, warmup, prof=True):
     return {
         "opt": opt, "sd": sd, "elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps,
         "frames_per_s": ctx.world * batch * steps / elapsed, "kern_ms": kern_ms, "points": points, "n_rays": n_rays,
-        "achieved": achieved, "frac": achieved / PEAK_TFLOPS[precision], "graph_replay": bool(rays == "R" and not prof and net.use_graph),
+        "achieved": achieved, "frac": achieved / PEAK_TFLOPS[precision],
+        "executed_tflops": points * flop_per_point_executed(precision) / (kern_ms * 1e-3) / 1e12, "graph_replay": bool(rays == "R" and not prof and net.use_graph),
         "workload": ("%s-R: %d heads/GPU/step, %dx%d rays x %d samples -> fused MLP+composite -> neural renderer "
                      "-> %dx%d RGB (+ background image)" % (config, batch, fs, fs, ns, pred, pred)) if rays == "R" else
                     ("%s-N: %d heads/GPU/step, 512x512 rays x %d samples, feature stage only" % (config, batch, ns)),
@@ -403,7 +416,7 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": r["kern_ms"], "points_per_launch": r["points"],
                 "flop_per_point_algorithmic": FLOP_PER_POINT,
-                "executed_tflops": r["points"] * FLOP_PER_POINT_EXECUTED / (r["kern_ms"] * 1e-3) / 1e12,
+                "executed_tflops": r["executed_tflops"],
             },
         }
     if ctx.world == 1:

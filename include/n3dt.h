@@ -148,7 +148,9 @@ int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, co
 
 /* ---- hierarchical (fine) sample planes: SURVEY 8f row 4 ------------------------------------------
  * Replaces FineSample.forward (NetWorks/utils.py:211-263): inverse-CDF resampling of the coarse pass.
- *   g         geometry of the COARSE pass (n_samples = N_c >= 3); its z_planes_given must be 0
+ *   g         geometry of the COARSE pass (n_samples = N_c >= 3).  z_planes_given = 0: the coarse planes are recomputed from
+ *             T and t_rand; 1: `t_rand` carries them, [B,N_r,N_c+1] (the far edge is not read) -- the fine_samp_func seam,
+ *             whose caller holds coarse_sample_dict["zvals"]
  *   n_fine    opt.num_sample_fine (N_f); n_fine + 1 samples are drawn
  *   weight    [B,N_r,N_c] compositing weights of the coarse pass (n3dt_render_fwd's `weight`)
  *   T, t_rand as given to the coarse pass (the coarse planes are recomputed from them)

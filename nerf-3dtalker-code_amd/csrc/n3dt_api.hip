@@ -297,7 +297,7 @@ extern "C" int n3dt_fine_sample(const N3dtGeom* g, int n_fine, const float* weig
     int rc = check_geom(g, N3DT_F32);
     if (rc) return rc;
     if (!weight || !T || !z_planes) return fail(N3DT_EINVAL, "n3dt_fine_sample: NULL argument");
-    if (g->z_planes_given) return fail(N3DT_EINVAL, "n3dt_fine_sample: the coarse pass must use the built-in planes");
+    if (g->z_planes_given && !t_rand) return fail(N3DT_EINVAL, "n3dt_fine_sample: z_planes_given but no coarse planes passed as t_rand");
     if (g->n_samples < 3) return fail(N3DT_EINVAL, "n3dt_fine_sample: needs at least 3 coarse samples");
     if (n_fine < 0 || g->n_samples + n_fine + 1 > 2048) return fail(N3DT_EINVAL, "n3dt_fine_sample: more than 2048 planes per ray");
     n3dt_launch_fine_sample(g, n_fine, weight, T, t_rand, u, z_planes, (hipStream_t)stream);

@@ -525,7 +525,8 @@ __global__ __launch_bounds__(64) void fine_sample_kernel(N3dtGeom g, int n_fine,
     const float* tr = t_rand ? t_rand + rayg * (Nc + 1) : nullptr;
     const float* w = weight + rayg * Nc;
     for (int j = lane; j < Nc; j += 64) {
-        const float z = n3dt_edge_z(rz1, rz2, j, Nc, tr);
+        // z_planes_given: the caller holds the coarse planes (the fine_samp_func seam gets them in coarse_sample_dict["zvals"])
+        const float z = g.z_planes_given ? tr[j] : n3dt_edge_z(rz1, rz2, j, Nc, tr);
         zc[j] = z;
         all[j] = z;
     }

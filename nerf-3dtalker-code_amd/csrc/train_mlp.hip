@@ -356,7 +356,10 @@ __global__ void train_camera_bwd_kernel(N3dtGeom g, const float* __restrict__ xy
             }
             dp[d] = acc;
         }
-        const float z_lo = n3dt_edge_z(rz1, rz2, s, Ns, tr), z_hi = n3dt_edge_z(rz1, rz2, s + 1, Ns, tr);
+        // hierarchical pass: the planes are given.  They are affine combinations (weights summing to 1, placed by the DETACHED
+        // coarse weights, NetWorks/utils.py:219-252) of the coarse planes o_z + const, so d plane / d T_z = 1 as in the coarse pass
+        const float z_lo = g.z_planes_given ? tr[s] : n3dt_edge_z(rz1, rz2, s, Ns, tr);
+        const float z_hi = g.z_planes_given ? tr[s + 1] : n3dt_edge_z(rz1, rz2, s + 1, Ns, tr);
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             g_dl[d] += dp[d] * z_lo;

@@ -280,15 +280,39 @@ class _NeuralRenderFn(torch.autograd.Function):
         return (None, d_feat, *[g.view(s) for g, s in zip(gt, ctx.shapes)])
 
 
-class _Seam(nn.Module):
-    """Parameter-less seam kept for attribute compatibility where no stand-alone operator exists (FineSample)."""
+class FineSample(nn.Module):
+    """fine_samp_func seam (NetWorks/utils.py:164-265) as a stand-alone operator with the reference's call:
+    `fine_samp_func(batch_weight [B,1,N_r,N_c], coarse_sample_dict, disturb)` -> {"pts", "dirs", "zvals", "z_dists"} on
+    the N_c + N_f sorted samples.  The planes come from n3dt_fine_sample (inverse CDF of the DETACHED interior weights,
+    stable merge with the coarse planes), the points from n3dt_sample_points on those planes.  forward() of the module
+    itself never materialises these tensors (HeadNeRFNet.fine_planes feeds the fused kernels directly)."""
 
-    def __init__(self, what):
+    def __init__(self, opt):
         super().__init__()
-        self.what = what
+        self.n_sample = opt.num_sample_fine + 1
+        self.world_z1, self.world_z2 = opt.world_z1, opt.world_z2
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("%s is fused into the render calls; use HeadNeRFNet.fine_planes()" % self.what)
+    @torch.no_grad()
+    def forward(self, batch_weight, coarse_sample_dict, disturb, fine_u=None):
+        cz = coarse_sample_dict["zvals"]
+        B, _, n_r, n_c = cz.shape
+        dev = cz.device
+        n_f = self.n_sample - 1
+        # the operators work from the camera, as the fused path does: recover it from the dict's ray tensors.  The coarse
+        # planes themselves are passed through (they are the dict's zvals plus the far edge the reference dropped).
+        ray_o = coarse_sample_dict["batch_ray_o"]                    # [B,3,N_r,1] (= T broadcast)
+        T = ops._f32c(ray_o[:, :, 0, 0])
+        if disturb and fine_u is None:                               # the reference's torch.rand(num_temp, NFsample)
+            fine_u = torch.rand(B * n_r, n_f + 1, device=dev, dtype=torch.float32)
+        geom = ops.make_geom(B, n_r, n_c, 384, 256, 179, 127, 64, 2, 1, self.world_z1, self.world_z2, z_planes_given=1)
+        coarse_planes = torch.nn.functional.pad(ops._f32c(cz).view(B, n_r, n_c), (0, 1))  # [B,N_r,N_c+1]; the far edge is not read
+        planes = ops.fine_sample(geom, n_f, ops._f32c(batch_weight).view(B, n_r, n_c), T, t_rand=coarse_planes,
+                                 u=None if fine_u is None else ops._f32c(fine_u))
+        zv = planes[:, :, :-1].unsqueeze(1)
+        ray_d, ray_l = coarse_sample_dict["batch_ray_d"], coarse_sample_dict["batch_ray_l"]
+        z_dists = (planes[:, :, 1:] - planes[:, :, :-1]).unsqueeze(1) * ray_l
+        pts = ray_o + ray_d * ray_l * zv
+        return {"pts": pts, "dirs": ray_d.expand(-1, -1, -1, zv.size(-1)), "zvals": zv, "z_dists": z_dists}
 
 
 class GenSamplePoints(nn.Module):
@@ -412,7 +436,7 @@ class HeadNeRFNet(nn.Module):
         self.fg_CD_predictor = MLPforNeRF(vp_channels=vp_channels, vd_channels=vd_channels, h_channel=self.mlp_h_channel,
                                           res_nfeat=self.featmap_nc, audio_dim=self.audio_dim)
         if self.hier_sampling:
-            self.fine_samp_func = _Seam("FineSample")
+            self.fine_samp_func = FineSample(self.opt)
             self.fine_fg_CD_predictor = MLPforNeRF(vp_channels=vp_channels, vd_channels=vd_channels, h_channel=self.mlp_h_channel,
                                                    res_nfeat=self.featmap_nc, audio_dim=self.audio_dim)
         self.calc_color_func = CalcRayColor()
@@ -649,8 +673,6 @@ class HeadNeRFNet(nn.Module):
                                 batch_Rmats, batch_Tvecs, shape_code, appea_code, audio, self.neural_render.bg_featmap, *mlp)
         passes = [merge.view(B, fs, fs, C)]
         if self.hier_sampling:
-            if any(torch.is_tensor(t) and t.requires_grad for t in (batch_Rmats, batch_Tvecs)):
-                raise NotImplementedError("camera gradients through the hierarchical pass are not built")
             with torch.no_grad():
                 w = self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
                                          t_rand=t_rand, want_weight=True, want_merge=False, precision=self.train_precision)["weight"]

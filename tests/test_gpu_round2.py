@@ -273,7 +273,7 @@ def test_config3_full_size_training_step():
         optim.zero_grad()
         loss.backward()
         optim.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and losses[2] < losses[0], losses
 
 
@@ -322,3 +322,65 @@ def test_graph_replay_is_bit_identical_to_the_kernel_by_kernel_path(precision, h
     assert not torch.equal(first, third) and len(graphed._graphs) == 2
     graphed.release_graphs()
     assert torch.equal(third, both(d3)["coarse_dict"]["merge_img"])
+
+
+@pytest.mark.parametrize("train_precision", ["fp32", "bf16"])
+def test_gradients_through_the_hierarchical_pass_including_the_cameras(train_precision):
+    """SURVEY 8f-1 x 8f-4 (VERDICT r1 missing #4): d loss / d (batch_Rmats, batch_Tvecs, latent codes) THROUGH coarse + fine
+    pass against the reference's autograd (tools/gen_golden.py: gen_hier -- the reference's own modules driven in
+    _forward's order with gradients enabled).  The fine planes move with the camera's z exactly like the coarse ones."""
+    from n3dt import HeadNeRFNet, synthetic as syn
+    from n3dt.train import data_losses, disk_mask
+    g, m = load_golden("hier_train")
+    opt, sd, inp = synthetic_case(m)
+    B, n_r = m["batch"], opt.featmap_size ** 2
+    net = HeadNeRFNet(opt, False, True, train_precision=train_precision).to(dev())
+    net.load_state_dict(sd, strict=True)
+    d = to_dev(inp)
+    names = ("batch_Rmats", "batch_Tvecs", "shape_code", "appea_code", "audiostyle")
+    for k in names:
+        d[k] = d[k].clone().requires_grad_(True)
+    t_rand = syn.stratified_noise(B, n_r, opt.num_sample_coarse, m["t_rand_seed"]).to(dev())
+    fine_u = torch.from_numpy(g["fine_u"]).to(dev())
+    out = net("train", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+              d["batch_Tvecs"], d["batch_inv_inmats"], t_rand=t_rand, fine_u=fine_u)
+    gt = torch.full_like(out["coarse_dict"]["merge_img"], 0.5)
+    mask = disk_mask(B, opt.pred_img_size).to(dev())
+    total = sum(data_losses(out["coarse_dict"], gt, mask).values()) + sum(data_losses(out["fine_dict"], gt, mask).values())
+    tol = {"fp32": (1e-3, 2e-3), "bf16": (3e-2, 0.35)}[train_precision]   # (loss rtol, gradient error / tensor scale)
+    np.testing.assert_allclose(float(total.detach()), float(g["loss_total"]), rtol=tol[0])
+    total.backward()
+    for k in names:
+        ref = g["grad_in." + k]
+        got = d[k].grad.cpu().numpy()
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
+        print("hier grads %s %s: max err / scale %.2e, cosine %.5f" % (train_precision, k, err, cos))
+        # the bf16 path's camera gradients carry the 2^k-amplified rounding of d PE (test_gpu_train.py: direction holds)
+        assert err <= (tol[1] if k.startswith("batch_") else min(tol[1], 0.1)), (k, err)
+        assert cos >= (0.9999 if train_precision == "fp32" else 0.98), (k, cos)
+
+
+def test_fine_samp_func_seam_has_the_reference_call():
+    """VERDICT r1 missing #5: net.fine_samp_func(batch_weight, coarse_sample_dict, disturb) (NetWorks/utils.py:211) on the
+    reference's own coarse weights -> the reference's fine zvals / z_dists / first-ray points (hier fixtures)."""
+    from n3dt import HeadNeRFNet, synthetic as syn
+    for name in ("hier_test", "hier_train"):
+        g, m = load_golden(name)
+        opt, sd, inp = synthetic_case(m)
+        B, n_r = m["batch"], opt.featmap_size ** 2
+        net = HeadNeRFNet(opt, False, True).to(dev())
+        net.load_state_dict(sd, strict=True)
+        d = to_dev(inp)
+        train = m["mode"] == "train"
+        t_rand = syn.stratified_noise(B, n_r, opt.num_sample_coarse, m["t_rand_seed"]).to(dev()) if train else None
+        coarse = net.sample_func(d["batch_xy"], d["batch_Rmats"], d["batch_Tvecs"], d["batch_inv_inmats"], train, t_rand=t_rand)
+        np.testing.assert_allclose(coarse["zvals"].cpu().numpy(), g["coarse_zvals"], atol=2e-6)
+        fine_u = torch.from_numpy(g["fine_u"]).to(dev()) if train else None
+        fine = net.fine_samp_func(torch.from_numpy(g["coarse_weight"]).to(dev()), coarse, train, fine_u=fine_u)
+        assert set(fine.keys()) == {"pts", "dirs", "zvals", "z_dists"}
+        N = opt.num_sample_coarse + opt.num_sample_fine
+        assert fine["pts"].shape == (B, 3, n_r, N) and fine["dirs"].shape == (B, 3, n_r, N)
+        np.testing.assert_allclose(fine["zvals"].cpu().numpy(), g["fine_zvals"], atol=2e-5)
+        np.testing.assert_allclose(fine["z_dists"].cpu().numpy(), g["fine_z_dists"], atol=2e-5)
+        np.testing.assert_allclose(fine["pts"][:, :, :1].cpu().numpy(), g["fine_pts_ray0"], atol=5e-5)

@@ -363,19 +363,39 @@ def gen_hier(HeadNeRFNet, name, fs, nc, nf, pred, B, mode):
         torch.rand = lambda *a, **k: fine_u.clone()
     colors = []
     hook = net.calc_color_func.register_forward_hook(lambda _m, _i, o: colors.append(o))
+
+    def run(inp):
+        fg = net.sample_func(inp["batch_xy"], inp["batch_Rmats"], inp["batch_Tvecs"], inp["batch_inv_inmats"], for_train)
+
+        def ex(code, n):
+            return code.unsqueeze(-1).unsqueeze(-1).expand(-1, -1, n_r, n)
+        pe = net.vp_encoder(fg["pts"])
+        c_res, w = net.calc_color_with_code(ex(inp["audiostyle"], nc), fg["pts"], ex(inp["shape_code"], nc),
+                                            ex(inp["appea_code"], nc), pe, None, fg["z_dists"], fg["zvals"], fine_level=False)
+        fine = net.fine_samp_func(w, fg, for_train)
+        fpe = net.vp_encoder(fine["pts"])
+        f_res, fw = net.calc_color_with_code(ex(inp["audiostyle"], N), fine["pts"], ex(inp["shape_code"], N),
+                                             ex(inp["appea_code"], N), fpe, None, fine["z_dists"], fine["zvals"], fine_level=True)
+        return fg, c_res, w, fine, f_res, fw
+    grads = {}
     try:
         with torch.no_grad():
-            fg = net.sample_func(inp["batch_xy"], inp["batch_Rmats"], inp["batch_Tvecs"], inp["batch_inv_inmats"], for_train)
-
-            def ex(code, n):
-                return code.unsqueeze(-1).unsqueeze(-1).expand(-1, -1, n_r, n)
-            pe = net.vp_encoder(fg["pts"])
-            c_res, w = net.calc_color_with_code(ex(inp["audiostyle"], nc), fg["pts"], ex(inp["shape_code"], nc),
-                                                ex(inp["appea_code"], nc), pe, None, fg["z_dists"], fg["zvals"], fine_level=False)
-            fine = net.fine_samp_func(w, fg, for_train)
-            fpe = net.vp_encoder(fine["pts"])
-            f_res, fw = net.calc_color_with_code(ex(inp["audiostyle"], N), fine["pts"], ex(inp["shape_code"], N),
-                                                 ex(inp["appea_code"], N), fpe, None, fine["z_dists"], fine["zvals"], fine_level=True)
+            fg, c_res, w, fine, f_res, fw = run(inp)
+        # single-image fitting differentiates the cameras and the latent codes THROUGH the hierarchical pass as well
+        # (FittingSingleImage_new.py:826-859 with hier_sampling; SURVEY 8f-1 x 8f-4): reference autograd of
+        # sum over (coarse image, fine image) of the three data terms
+        ginp = dict(inp)
+        for k in ("batch_Rmats", "batch_Tvecs", "shape_code", "appea_code", "audiostyle"):
+            ginp[k] = inp[k].clone().requires_grad_(True)
+        _, gc, _, _, gf, _ = run(ginp)
+        gt = torch.full_like(gc["merge_img"], 0.5)
+        mask = disk_mask(B, pred)
+        total = sum(losses(gc, gt, mask)) + sum(losses(gf, gt, mask))
+        total.backward()
+        for k in ("batch_Rmats", "batch_Tvecs", "shape_code", "appea_code", "audiostyle"):
+            grads["grad_in." + k] = np32(ginp[k].grad)
+        grads["loss_total"] = np.float64(total.item())
+        colors = colors[:2]
     finally:
         hook.remove()
         torch.rand_like, torch.rand = orig_rand_like, orig_rand
@@ -387,6 +407,7 @@ def gen_hier(HeadNeRFNet, name, fs, nc, nf, pred, B, mode):
     }
     if for_train:
         arrays["fine_u"] = np32(fine_u)
+    arrays.update(grads)
     save(name, arrays, manifest_base(name, opt, {
         "batch": B, "mode": mode, "weights_seed": 0, "bg_noise": 0.1, "yaw_range": 0.3, "hier_sampling": True,
         "num_sample_fine": nf, "t_rand_seed": 7, "fine_u_seed": 11,
