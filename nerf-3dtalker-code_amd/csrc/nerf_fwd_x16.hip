@@ -31,6 +31,7 @@
 template <int PREC>
 struct X16SaveStage {
     unsigned char* tile0;  // per-lane pointer (lane * 16 included); nullptr on dead blocks
+    unsigned* gate0;       // per-lane pointer to this layer's 6 gate words (64 words apart); nullptr: none
     typename X16<PREC>::frag I0, I1;
 };
 
@@ -44,6 +45,7 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
     static_assert(!SAVE || NB == 1, "the training forward runs one block per wave");
     const int h = lane >> 5, c = lane & 31;
     float red[NB][32];
+    unsigned gate_word = 0;
     const frag ones = X16<PREC>::ones_frag();
     float bias_cur = bias[c];
     constexpr bool PACKS = (MODE == MODE_HIDDEN || MODE == MODE_LINEAR);
@@ -98,6 +100,22 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
         }
         if constexpr (SAVE && PACKS) {
             if (sv->tile0) x16_transpose_store<PREC>(hout[0][2 * ot], hout[0][2 * ot + 1], sv->I0, sv->I1, sv->tile0 + ot * 2 * X16_PIECE);
+            // ReLU gates of the backward chain: bit 8*half + j of this tile's half-word = "stored activation > 0" of accumulator
+            // register 8*half + j (same lane, same tile, same register in nerf_bwd_x16_kernel); two tiles share a 32-bit word
+            unsigned m = 0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const s16x8 hv = __builtin_bit_cast(s16x8, hout[0][2 * ot + half]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m |= (hv[j] != 0 ? 1u : 0u) << (8 * half + j);
+            }
+            // (v_pk_min_u16 + v_dot2_u32_u16 per packed pair would be 16 operations per tile instead of ~48, but hipcc expands
+            // the packed min into compares and selects anyway and the dot2 result came out wrong on gfx950: not used)
+            if constexpr (ot & 1) {
+                if (sv->gate0) sv->gate0[(ot >> 1) * 64] = gate_word | (m << 16);
+            } else {
+                gate_word = m;
+            }
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -140,10 +158,12 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
 //   xT   X16_XT_TILES tiles of 2 KiB: PE (2 tiles) | H0 .. H7 (12 tiles each), lane = channel pieces
 //   gS   12 lane = sample fragments of relu(RGB_layer_1)
 //   geo  density pre-activation [32] | plane distance [32]
+//   gates  8 layers x 6 words x 64 lanes: the sign bits of H0 .. H7 in accumulator order (the dX chain's ReLU gates)
 struct X16TrainSave {
     unsigned char* xT;
     unsigned char* gS;
     float* geo;
+    unsigned* gates;
 };
 
 template <int PREC, int NB, int WAVES, bool SAVE = false>
@@ -151,7 +171,7 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
     const N3dtGeom& g, const unsigned char* __restrict__ packed, const float* __restrict__ fold, const float* __restrict__ xy,
     const float* __restrict__ R, const float* __restrict__ T, const float* __restrict__ Kinv, const float* __restrict__ t_rand,
     float* __restrict__ part, float* __restrict__ wlocal, int bpr, long total_blocks, unsigned char* lds, const int wave,
-    const X16TrainSave tsv = X16TrainSave{nullptr, nullptr, nullptr}) {
+    const X16TrainSave tsv = X16TrainSave{nullptr, nullptr, nullptr, nullptr}) {
     typedef typename X16<PREC>::frag frag;
     const int lane = threadIdx.x & 63;
     const int c = lane & 31, h = lane >> 5;
@@ -221,6 +241,7 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
     auto sv_hidden = [&](const int l) -> const X16SaveStage<PREC>* {
         if constexpr (SAVE) {
             svs.tile0 = xT_blk ? xT_blk + (size_t)(2 + 12 * l) * 2 * X16_PIECE : nullptr;
+            svs.gate0 = xT_blk ? tsv.gates + ((size_t)blk[0] * 8 + l) * 6 * 64 + lane : nullptr;
             return &svs;
         } else {
             return nullptr;
@@ -280,7 +301,10 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
     }
     // RGB_layer_0 -> RGB_layer_1 as ONE merged 192 x 384 layer on h7 (no activation sits between them, models.py:79-81;
     // merged matrix and bias built by pack / fold), relu, weighted by the sample weights and reduced over the samples
-    if constexpr (SAVE) svs.tile0 = live[0] ? tsv.gS + (size_t)blk[0] * 12 * X16_PIECE + lane * 16 : nullptr;
+    if constexpr (SAVE) {
+        svs.tile0 = live[0] ? tsv.gS + (size_t)blk[0] * 12 * X16_PIECE + lane * 16 : nullptr;
+        svs.gate0 = nullptr;
+    }
     x16_stage<PREC, NB, WAVES, 24, 0, 6, MODE_COMPOSITE, SAVE>(ws, fb + n3dt_bias_offset(10), pe, nullptr, hb, ha, aux, po, live, lane,
                                                                      SAVE ? &svs : nullptr);
 #ifdef X16_STAMP
@@ -321,7 +345,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerf_fwd_x16_train_kernel(
 #endif
 extern "C" void n3dt_launch_nerf_fwd_x16_train(const N3dtGeom* g, const void* packed, const float* fold, const float* xy, const float* R,
                                                const float* T, const float* Kinv, const float* t_rand, float* part, float* wlocal,
-                                               void* xT, void* gS, float* geo, hipStream_t stream) {
+                                               void* xT, void* gS, float* geo, void* gates, hipStream_t stream) {
     constexpr int WAVES = X16_TRAIN_WAVES;
     const int bpr = (g->n_samples + X16_BS - 1) / X16_BS;
     const long total = (long)g->batch * g->n_rays * bpr;
@@ -329,7 +353,7 @@ extern "C" void n3dt_launch_nerf_fwd_x16_train(const N3dtGeom* g, const void* pa
     const size_t lds_bytes = X16_NBUF * X16_CH * X16_PIECE + (size_t)WAVES * 4 * X16_PIECE;
     auto kern = nerf_fwd_x16_train_kernel<WAVES>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    X16TrainSave tsv{reinterpret_cast<unsigned char*>(xT), reinterpret_cast<unsigned char*>(gS), geo};
+    X16TrainSave tsv{reinterpret_cast<unsigned char*>(xT), reinterpret_cast<unsigned char*>(gS), geo, reinterpret_cast<unsigned*>(gates)};
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, *g, reinterpret_cast<const unsigned char*>(packed), fold, xy,
                        R, T, Kinv, t_rand, part, wlocal, bpr, total, tsv);
 }
