@@ -378,10 +378,14 @@ class HeadNeRFNet(nn.Module):
         self._build_tool_funcs()
         self.neural_render.train_precision = train_precision
         self._pack_cache = {}
-        # mode="test" forwards are recorded once per call shape into a hipGraph and replayed with one launch (see
-        # _forward_graph); N3DT_GRAPH=0 / use_graph=False keeps the kernel-by-kernel path.  graph_static_outputs=True
-        # returns views of the graph's own output buffer (valid until the next forward of the same shape) instead of a copy.
-        self.use_graph = (os.environ.get("N3DT_GRAPH", "1") != "0") if use_graph is None else bool(use_graph)
+        # use_graph=True (or N3DT_GRAPH=1): mode="test" forwards are recorded once per call shape into a hipGraph and replayed
+        # with one launch (see _forward_graph).  OFF by default: measured on MI355X / ROCm 7.2 a replay is 3-7 % SLOWER than the
+        # stream-ordered launches it replaces (one head: 0.72-0.74 ms against 0.68-0.70; config 4: 5 570 against 5 980 frames/s)
+        # -- the forward is GPU-bound even at one head, its launches were already hidden behind the kernels, and the replay adds
+        # per-node scheduling.  It remains for hosts whose CPU is the bottleneck (the per-forward host cost drops to three calls).
+        # graph_static_outputs=True returns views of the graph's own output buffer (valid until the next forward of the same
+        # shape) instead of a copy.
+        self.use_graph = (os.environ.get("N3DT_GRAPH", "0") == "1") if use_graph is None else bool(use_graph)
         self.graph_static_outputs = graph_static_outputs
         self._graphs = {}
         self._bg_cache = None
