@@ -581,7 +581,7 @@ class HeadNeRFNet(nn.Module):
         sig = self._param_signature()
         e = self._graphs.get(key)
         if e is not None and e["sig"] != sig:  # parameters were re-allocated (e.g. .to(), a new bg_featmap): record again
-            ops.graph_destroy(e["graph"])
+            self._drop_graph(self._graphs.pop(key))
             e = None
         xy = batch_xy if batch_xy.dtype == torch.float32 else batch_xy.float()
         small = [ops._f32c(t) for t in (batch_Rmats, batch_Tvecs, batch_inv_inmats, shape_code, appea_code)]
@@ -589,8 +589,7 @@ class HeadNeRFNet(nn.Module):
             small.append(ops._f32c(audiostyle))
         if e is None:
             if len(self._graphs) >= 8:  # a handful of call shapes per model in practice; do not grow without bound
-                old = self._graphs.pop(next(iter(self._graphs)))
-                ops.graph_destroy(old["graph"])
+                self._drop_graph(self._graphs.pop(next(iter(self._graphs))))
             e = self._graphs[key] = self._record_graph(B, n_r, dev, sig, xy, small)
         # packed weights follow the parameters' version counters; re-packed in place, so the recorded address stays valid
         for fine in ((False, True) if self.hier_sampling else (False,)):
@@ -623,6 +622,8 @@ class HeadNeRFNet(nn.Module):
         geom = e["geom"] = self._geom(B, n_r, e["xy"])
         bufs = {"render_ws": torch.empty(ops.render_workspace_bytes(geom, prec), dtype=torch.uint8, device=dev),
                 "nr_ws": torch.empty(ops.neural_render_workspace_bytes(self.neural_render._geom(nb + 1), nb + 1), dtype=torch.uint8, device=dev)}
+        # a freshly allocated workspace may sit where a released one sat: whatever was recorded for that address is void
+        self.neural_render._packed_sig.pop(bufs["nr_ws"].data_ptr(), None)
         packed = {}
         if self.hier_sampling:
             n_fine = self.num_sample_coarse + self.num_sample_fine
@@ -649,10 +650,14 @@ class HeadNeRFNet(nn.Module):
                 e["graph"] = ops.graph_end(side)
         return e
 
+    def _drop_graph(self, e):
+        ops.graph_destroy(e["graph"])
+        self.neural_render._packed_sig.pop(e["bufs"]["nr_ws"].data_ptr(), None)  # the workspace goes back to the allocator
+
     def release_graphs(self):
         """Destroy the recorded hipGraphs and their static buffers (they are re-recorded on demand)."""
         for e in self._graphs.values():
-            ops.graph_destroy(e["graph"])
+            self._drop_graph(e)
         self._graphs.clear()
 
     def __del__(self):
