@@ -209,7 +209,8 @@ def run_train(ctx, config, train_precision, batch, steps, warmup, audio2style_bu
     from n3dt.train import fused_data_losses as data_losses, disk_mask
     opt, sd, net, d = build(ctx, config, "fp32", batch, "R", train_precision=train_precision)
     fs, ns, pred = GEOMETRY[config]
-    optim = torch.optim.Adam(net.parameters(), lr=1e-4)
+    # the reference's Adam (talker_trainer.py:722-723), as PyTorch's single-kernel ("fused") implementation of the same update
+    optim = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
     bucket = optim_a2s = None
     if audio2style_bucket and ctx.world > 1:
         bucket = parallel.FlatBucket().to(ctx.dev)
