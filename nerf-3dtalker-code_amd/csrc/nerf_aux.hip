@@ -36,15 +36,32 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int N, int K, co
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        for (int i = t; i < 1024; i += 256) {
+    // the next k-slab's 4 + 4 elements per thread are fetched into registers while the current one is multiplied: the loop
+    // used to be load -> barrier -> 32 FMAs -> barrier, twelve exposed global-load latencies in a row (43 us for 192 x 384 x 384)
+    float ra[4], rb[4];
+    auto fetch = [&](const int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = t + 256 * u;
             // pick the index that is contiguous in memory as the fast one
             const int a_r = sak == 1 ? i >> 5 : i & 31, a_k = sak == 1 ? i & 31 : i >> 5;
             const int b_r = sbk == 1 ? i >> 5 : i & 31, b_k = sbk == 1 ? i & 31 : i >> 5;
-            As[a_k][a_r] = (m0 + a_r < M && k0 + a_k < K) ? A[(long)(m0 + a_r) * sam + (long)(k0 + a_k) * sak] : 0.0f;
-            Bs[b_k][b_r] = (n0 + b_r < N && k0 + b_k < K) ? Bm[(long)(n0 + b_r) * sbn + (long)(k0 + b_k) * sbk] : 0.0f;
+            ra[u] = (m0 + a_r < M && k0 + a_k < K) ? A[(long)(m0 + a_r) * sam + (long)(k0 + a_k) * sak] : 0.0f;
+            rb[u] = (n0 + b_r < N && k0 + b_k < K) ? Bm[(long)(n0 + b_r) * sbn + (long)(k0 + b_k) * sbk] : 0.0f;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = t + 256 * u;
+            const int a_r = sak == 1 ? i >> 5 : i & 31, a_k = sak == 1 ? i & 31 : i >> 5;
+            const int b_r = sbk == 1 ? i >> 5 : i & 31, b_k = sbk == 1 ? i & 31 : i >> 5;
+            As[a_k][a_r] = ra[u];
+            Bs[b_k][b_r] = rb[u];
         }
         __syncthreads();
+        if (k0 + 32 < K) fetch(k0 + 32);
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
             const float a0 = As[k][ty], a1 = As[k][ty + 16], b0 = Bs[k][tx], b1 = Bs[k][tx + 16];
