@@ -639,17 +639,33 @@ __global__ __launch_bounds__(256) void nrt_dw16_kernel(int co, int ci, long K, c
             if (ch < co) atomicAdd(db + ch, (rs_red[0][i] + rs_red[1][i]) + (rs_red[2][i] + rs_red[3][i]));
         }
     }
-    if (p0 >= p1) return;
+    // The four waves of the workgroup hold four partial sums of the SAME output tiles (disjoint pixel ranges).  They are
+    // combined through LDS first -- wave w sums tile t of all four for t % 4 == w -- and only then added to the result: a
+    // quarter of the fp32 atomics (disabling them showed they were 40 % of the kernel: 83 -> 50 us per launch).
+    extern __shared__ float wave_acc[];  // [4 waves][TO*TI tiles][16][64]
+    constexpr int NT = TO * TI;
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int b = 0; b < TI; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) wave_acc[((wave * NT + a * TI + b) * 16 + q) * 64 + lane] = acc[a][b][q];
+    __syncthreads();
 #pragma unroll
     for (int a = 0; a < TO; ++a)
 #pragma unroll
         for (int b = 0; b < TI; ++b) {
+            const int tl = a * TI + b;
+            if ((tl & 3) != wave) continue;  // uniform per wave
             const int col = i0 + 32 * b + r;
             if (col >= ci) continue;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = o0 + 32 * a + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (row < co) atomicAdd(out + (long)row * ldo + col, acc[a][b][q]);
+                float v = 0.0f;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) v += wave_acc[((w4 * NT + tl) * 16 + q) * 64 + lane];
+                if (row < co) atomicAdd(out + (long)row * ldo + col, v);
             }
         }
 }
@@ -662,8 +678,15 @@ static void launch_dw16(int co, int ci, long K, const nrt_bf16* dY, const TX* X,
     if (slices < 1) slices = 1;
     const long chunk = ((K + slices - 1) / slices + 63) / 64 * 64;
     dim3 grid((unsigned)((K + chunk - 1) / chunk), groups);
-    if (co <= 32 && ci <= 64) hipLaunchKernelGGL((nrt_dw16_kernel<1, 2, TX>), dim3(grid.x, 1), dim3(256), 0, s, co, ci, K, dY, X, out, ldo, chunk, db);
-    else hipLaunchKernelGGL((nrt_dw16_kernel<2, 4, TX>), grid, dim3(256), 0, s, co, ci, K, dY, X, out, ldo, chunk, db);
+    if (co <= 32 && ci <= 64) {
+        hipLaunchKernelGGL((nrt_dw16_kernel<1, 2, TX>), dim3(grid.x, 1), dim3(256), (size_t)4 * 2 * 16 * 64 * sizeof(float), s, co, ci, K, dY, X, out,
+                           ldo, chunk, db);
+    } else {
+        auto kern = nrt_dw16_kernel<2, 4, TX>;
+        const size_t lds = (size_t)4 * 8 * 16 * 64 * sizeof(float);  // 128 KiB
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, co, ci, K, dY, X, out, ldo, chunk, db);
+    }
 }
 
 // to fp32 at the boundary (d_featmap is fp32 in both modes)
