@@ -251,6 +251,37 @@ def run_train(ctx, config, train_precision, batch, steps, warmup, audio2style_bu
     }
 
 
+def run_fit(ctx, config, train_precision, steps, warmup):
+    """Single-image fitting (FittingSingleImage_new.py:825-916): B = 1, forward("test") WITH gradients to the codes and the
+    camera -> 3 MSE terms -> backward -> Adam on five small tensors; the network's parameters are frozen."""
+    import torch
+    from n3dt import fitting
+    from n3dt.train import fused_data_losses as data_losses, disk_mask
+    opt, sd, net, d = build(ctx, config, "fp32", 1, "R", train_precision=train_precision)
+    fs, ns, pred = GEOMETRY[config]
+    for p in net.parameters():
+        p.requires_grad_(False)
+    st = fitting.FittingState(d["shape_code"], d["appea_code"], {k: d[k] for k in ("batch_Rmats", "batch_Tvecs", "batch_inv_inmats")})
+    optim, sched = st.make_optimizer()
+    gt = torch.full((1, 3, pred, pred), 0.5, device=ctx.dev)
+    mask = disk_mask(1, pred).to(ctx.dev)
+
+    def step():
+        fitting.fit_step(net, st, optim, sched, d["batch_xy"], d["batch_uv"], d["audiostyle"], gt, mask, data_losses)
+
+    for _ in range(warmup):
+        step()
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.barrier()
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    return {"elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "frames_per_s": ctx.world * steps / elapsed,
+            "workload": "%s fitting: 1 head/step, %dx%d rays x %d samples -> %dx%d, gradients to codes + camera, Adam on 5 tensors" % (
+                config, fs, fs, ns, pred, pred)}
+
+
 def cpu_info():
     model = "unknown"
     try:
@@ -323,6 +354,8 @@ def extras(ctx):
     rec("cfg3_train_fp32_b2", "exact fp32 training path", lambda k, w: run_train(ctx, "cfg2", "fp32", 2, k, w), 4, 2)
     rec("cfg4_bf16_b4", "bf16", lambda k, w: run_render(ctx, "cfg4", "bf16", 4, "R", k, w, prof=False), 20, 5)
     rec("cfg4_train_bf16_b2", "fused bf16 training path", lambda k, w: run_train(ctx, "cfg4", "bf16", 2, k, w), 5, 2)
+    rec("cfg4_fit_bf16_b1", "single-image fitting iteration (256^2 geometry, as model_Reso32), fused bf16 training path",
+        lambda k, w: run_fit(ctx, "cfg4", "bf16", k, w), 10, 3)
     rec("cfg5_bf16_b4", "bf16", lambda k, w: run_render(ctx, "cfg5", "bf16", 4, "R", k, w, prof=False), 10, 3)
     return out
 

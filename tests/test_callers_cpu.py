@@ -67,3 +67,31 @@ def test_oracle_on_the_contrast_fixture():
     # vs the oracle's): 1e-6 on the raw head becomes 4e-4 on sigma; measured 2e-4 on bg_alpha
     np.testing.assert_allclose(out["bg_alpha"], g["bg_alpha"], atol=1e-3)
     assert np.abs(out["merge_img"] - g["merge_img_q16"].astype(np.float32) / 65535.0).max() <= 1e-3
+
+
+def test_fitting_camera_parametrisation():
+    """n3dt.fitting: Euler -> rotation (Rz Ry Rx, FittingSingleImage_new.py:736-766) against scipy, its autograd against finite
+    differences, and the camera composition R = dR R0, T = dR T0 + dT (:797-803)."""
+    from scipy.spatial.transform import Rotation
+    from n3dt import fitting
+    g = torch.Generator().manual_seed(3)
+    ang = (torch.rand(5, 3, generator=g, dtype=torch.float64) - 0.5) * 2.0
+    R = fitting.eulurangle2Rmat(ang)
+    ref = Rotation.from_euler("xyz", ang.numpy()).as_matrix()  # extrinsic x, y, z = Rz Ry Rx
+    np.testing.assert_allclose(R.numpy(), ref, atol=1e-12)
+    assert torch.autograd.gradcheck(fitting.eulurangle2Rmat, (ang.clone().requires_grad_(True),), eps=1e-6, atol=1e-6)
+    base_shape, base_appea = torch.zeros(1, 179), torch.zeros(1, 127)
+    cam = {"batch_Rmats": torch.diag(torch.tensor([1.0, -1.0, -1.0])).view(1, 3, 3), "batch_Tvecs": torch.tensor([[[0.0], [0.0], [12.0]]]),
+           "batch_inv_inmats": torch.eye(3).view(1, 3, 3)}
+    st = fitting.FittingState(base_shape, base_appea, cam)
+    code, c0 = st.build_code_and_cam()
+    assert torch.equal(c0["batch_Rmats"], cam["batch_Rmats"]) and torch.equal(c0["batch_Tvecs"], cam["batch_Tvecs"])
+    assert code["shape_code"].shape == (1, 179) and code["bg_code"] is None
+    with torch.no_grad():
+        st.delta_EulurAngles.copy_(torch.tensor([[0.0, 0.3, 0.0]]))
+        st.delta_Tvecs.copy_(torch.tensor([[[0.1], [0.0], [0.0]]]))
+    _, c1 = st.build_code_and_cam()
+    dR = fitting.eulurangle2Rmat(st.delta_EulurAngles)
+    np.testing.assert_allclose(c1["batch_Tvecs"].detach().numpy(), (dR.detach() @ cam["batch_Tvecs"] + st.delta_Tvecs.detach()).numpy(), atol=1e-7)
+    opt, sched = st.make_optimizer()
+    assert [g_["lr"] for g_ in opt.param_groups] == [0.015, 0.015, 0.01, 0.001, 0.001]
