@@ -77,6 +77,47 @@ def fused_data_losses(coarse, gt_rgb, mask, bg_value=1.0):
     return {"bg_loss": t[0], "head_loss": t[1], "nonhead_loss": t[2]}
 
 
+class HeadNeRFLossUtils(object):
+    """Drop-in for the reference's loss object (Utils/HeadNeRFLossUtils.py:66-236) on the fused HIP loss tail: same
+    constructor, same `calc_total_loss(delta_cam_info, opt_code_dict, pred_dict, gt_rgb, mask_tensor, disp_pred_dict)` call,
+    same result keys -- including the reference's spelling `nonhaed_loss` -- so the trainer's and the fitting script's loss lines
+    (talker_trainer.py:1058, FittingSingleImage_new.py:894) stay as they are.  The VGG perceptual term needs torchvision's
+    pretrained VGG16, which is outside the accelerated path: `use_vgg_loss=True` is refused, add that term in the caller."""
+
+    def __init__(self, bg_type="white", use_vgg_loss=True, device=None):
+        if bg_type == "white":
+            self.bg_value = 1.0
+        elif bg_type == "black":
+            self.bg_value = 0.0
+        else:
+            raise ValueError("Error BG type. ")  # the reference prints this and exit(0)s
+        if use_vgg_loss:
+            raise NotImplementedError("the VGG perceptual term is not part of the accelerated path: construct with "
+                                      "use_vgg_loss=False and add the reference's VGGPerceptualLoss to total_loss yourself")
+        self.use_vgg_loss = False
+        self.device = device
+
+    def calc_data_loss(self, data_dict, gt_rgb, head_mask_c1b, nonhead_mask_c1b):
+        """The reference passes the two boolean masks of `mask >= 0.5` / `mask < 0.5` (:200-201); the kernel takes the mask itself."""
+        if not (nonhead_mask_c1b.dtype == torch.bool and head_mask_c1b.dtype == torch.bool):
+            raise TypeError("calc_data_loss expects the boolean masks calc_total_loss builds")
+        if bool((head_mask_c1b == nonhead_mask_c1b).any()):
+            raise ValueError("head and non-head masks must be complementary (the fused kernel classifies each pixel once)")
+        t = fused_data_losses(data_dict, gt_rgb, head_mask_c1b.to(gt_rgb.dtype), self.bg_value)
+        return {"bg_loss": t["bg_loss"], "head_loss": t["head_loss"], "nonhaed_loss": t["nonhead_loss"]}
+
+    def calc_total_loss(self, delta_cam_info, opt_code_dict, pred_dict, gt_rgb, mask_tensor, disp_pred_dict, eye_mask_tensor=None):
+        """bg + head + non-head data terms and their sum (:196-236; the camera / code / eye / displacement terms are commented
+        out in the reference, so the first two and the last two arguments are accepted and unused, as there)."""
+        t = fused_data_losses(pred_dict["coarse_dict"], gt_rgb, mask_tensor, self.bg_value)
+        loss_dict = {"bg_loss": t["bg_loss"], "head_loss": t["head_loss"], "nonhaed_loss": t["nonhead_loss"]}
+        total_loss = 0.0
+        for k in loss_dict:
+            total_loss += loss_dict[k]
+        loss_dict["total_loss"] = total_loss
+        return loss_dict
+
+
 def make_optimizer(net, lr=1e-4):
     """Adam + StepLR as the reference builds them (talker_trainer.py:722-727)."""
     opt = torch.optim.Adam(net.parameters(), lr=lr)

@@ -181,6 +181,15 @@ def test_fused_loss_tail_against_the_reference(case):
     total.backward()
     np.testing.assert_allclose(merge.grad.cpu().numpy(), g[k + "d_merge"], atol=1e-9, rtol=1e-5)
     np.testing.assert_allclose(bg.grad.cpu().numpy(), g[k + "d_bg"], atol=1e-9, rtol=1e-5)
+    # the same through the reference-shaped object (same call, same keys incl. the reference's `nonhaed_loss`)
+    from n3dt.train import HeadNeRFLossUtils
+    lu = HeadNeRFLossUtils(bg_type=info["bg_type"], use_vgg_loss=False)
+    res = lu.calc_total_loss(None, None, {"coarse_dict": {"merge_img": merge.detach(), "bg_img": bg.detach()}},
+                             torch.from_numpy(g[k + "gt"]).to(dev()), torch.from_numpy(g[k + "mask"]).to(dev()), None)
+    assert list(res.keys()) == ["bg_loss", "head_loss", "nonhaed_loss", "total_loss"]
+    np.testing.assert_allclose([float(res[n]) for n in res], g[k + "terms"], rtol=2e-6)
+    with pytest.raises(NotImplementedError):
+        HeadNeRFLossUtils(bg_type="white", use_vgg_loss=True)
     with pytest.raises(ValueError):  # a [B,3,P,P] background is not what the kernel is built for: refuse, do not misread
         fused_data_losses({"merge_img": merge, "bg_img": bg.expand(2, -1, -1, -1)}, torch.from_numpy(g[k + "gt"]).to(dev()),
                           torch.from_numpy(g[k + "mask"]).to(dev()))
