@@ -435,3 +435,28 @@ def test_single_image_fitting_loop_recovers_a_perturbed_camera_and_codes(train_p
     # (the camera / code gradients themselves are pinned against the reference's autograd in test_gpu_train.py and in
     # test_gradients_through_the_hierarchical_pass_including_the_cameras; this test is about the loop using them)
     assert float(st.delta_EulurAngles.detach().abs().max()) > 1e-3 and float(st.iden_offset.detach().abs().max()) > 1e-2
+
+
+def test_split_precision_mode_properties_at_full_size():
+    """precision="bf16x3" at the BASELINE size (fs 64, 64 samples, B = 8): size-independent properties -- bit-determinism,
+    weights a sub-probability distribution, frame independence -- and agreement with the exact-fp32 kernel on the same inputs
+    (feature maps 1e-4, RGB 2e-4: the two parity-grade modes against each other, no stored answer needed)."""
+    from n3dt import BaseOptions, synthetic as syn
+    opt = BaseOptions({"featmap_size": 64, "featmap_nc": 256, "pred_img_size": 512, "num_sample_coarse": 64})
+    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
+    d = to_dev(syn.frame_inputs(opt, 8))
+    net = build_net(opt, sd, "bf16x3")
+    a = feats(net, d, want_weight=True)
+    b = feats(net, d, want_weight=True)
+    assert torch.equal(a["fg_feat"], b["fg_feat"]) and torch.equal(a["bg_alpha"], b["bg_alpha"])
+    w = a["weight"]
+    assert float(w.min()) >= 0.0 and float((w.sum(-1) + a["bg_alpha"] - 1.0).abs().max()) <= 1e-5
+    one = {k: (v[5:6] if torch.is_tensor(v) else v) for k, v in d.items()}
+    assert torch.equal(feats(net, one)["fg_feat"][0], a["fg_feat"][5])
+    ref = build_net(opt, sd, "fp32")
+    r = feats(ref, d)
+    assert float((a["fg_feat"] - r["fg_feat"]).abs().max()) <= 1e-4
+    img, img_ref = fwd(net, d)["merge_img"], fwd(ref, d)["merge_img"]
+    err = float((img - img_ref).abs().max())
+    print("bf16x3 vs fp32 at 8 x 512^2: RGB max|diff| %.2e" % err)
+    assert err <= 2e-4
