@@ -20,34 +20,71 @@
 #include "x16_core.h"
 
 
+#ifndef X16_SAVE_DEPTH
+#define X16_SAVE_DEPTH 3
+#endif
 // One stage: out[N x 32*NB] = W'[N x K] . in[K x 32*NB] + bias (+ activation), NT = N/32 out tiles.
 // The KPE leading k-steps take their B operand from the wave's PE fragments: registers (pe_reg,
 // stage L0) or the wave's LDS copy (pe_lds, skip stage L5); the rest come from hin.
 // `bias` is wave-uniform, so the 32 values of a tile arrive by scalar loads; lane half h picks
 // rows (r&3)+8(r>>2)+4h of the tile.
 // SAVE (training forward, NB == 1): every finished output tile is also written to HBM for the backward -- hidden
-// tiles transposed to lane = channel pieces (x16_core.h) at sv.tile0 + 2 KiB * tile, the RGB_layer_1 activations as
-// they are (lane = sample fragments) at sv.tile0 + 1 KiB * k-step.
+// tiles as [sample][channel] images (x16_core.h: x16_image_store) at sv.tile0 + 2 KiB * tile, the RGB_layer_1 activations
+// lane-linear (lane = sample fragments) at sv.tile0 + 1 KiB * k-step.
 template <int PREC>
 struct X16SaveStage {
-    unsigned char* tile0;  // per-lane pointer (lane * 16 included); nullptr on dead blocks
-    unsigned* gate0;       // per-lane pointer to this layer's 6 gate words (64 words apart); nullptr: none
-    typename X16<PREC>::frag I0, I1;
+    unsigned char* tile0;  // per-lane pointer (image offset, or lane * 16 for the lane-linear fragments, included)
+    unsigned* gate0;       // per-lane pointer to this layer's 6 gate words (64 words apart)
 };
 
-template <int PREC, int NB, int WAVES, int KS, int KPE, int NT, int MODE, bool SAVE = false>
-__device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const float* __restrict__ bias,
+// Biases of the training forward come from LDS.  vmcnt retires in order, so hipcc's wait for a bias LOAD also waits for every
+// store issued before it: with the inference form (a global load one tile ahead) each tile began by waiting for the previous
+// tile's 2-3 KiB of saved-tile stores to be acknowledged, while the write path runs near the HBM write bandwidth -- 0.2 ms of
+// the 1.65 ms kernel (diagnostic build without the loads).  Here every wave copies the next stage's bias table (<= 1.5 KiB) into
+// its own LDS slot by LDS-DMA a stage ahead (X16BiasLds::stage_in; complete by the next rendezvous wait, which leaves only
+// the stores issued since outstanding), and a tile's value is read with an asm ds_read_b32 issued a tile ahead: LDS returns in
+// order, so it has landed once any later weight fragment has been awaited -- no wait of its own, nothing on vmcnt.
+#define X16_BIAS_SLOT 1536  // bytes: 384 floats
+#ifndef X16_SAVE_LDS_BIAS
+#define X16_SAVE_LDS_BIAS 1
+#endif
+struct X16BiasLds {
+    unsigned char* slots;  // this wave's two slots (generic pointer, wave-uniform)
+    unsigned addr;         // LDS byte address of slot 0 + 4 * (lane & 31)
+    // table -> slot by LDS-DMA: n floats (a multiple of 64), 256 B per instruction, lane-linear
+    __device__ __forceinline__ void stage_in(const float* table, const int n, const int slot, const int lane) const {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (64 * i < n)
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(table + 64 * i + lane), (LDS_AS void*)(slots + slot * X16_BIAS_SLOT + 256 * i), 4, 0, 0);
+    }
+};
+template <int OFF>
+__device__ __forceinline__ void x16_bias_read(float& dst, const unsigned addr) {
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
+}
+
+template <int PREC, int NB, int WAVES, int KS, int KPE, int NT, int MODE, bool SAVE = false, class WS>
+__device__ __forceinline__ void x16_stage(WS& ws, const float* __restrict__ bias,
                                           const typename X16<PREC>::frag (&pe_reg)[NB][4], const unsigned char* pe_lds,
                                           const typename X16<PREC>::frag (&hin)[NB][24], typename X16<PREC>::frag (&hout)[NB][24],
                                           float (&aux)[NB], float* const (&po)[NB], const bool (&live)[NB], const int lane,
-                                          const X16SaveStage<PREC>* sv = nullptr, const short relu_lo = 0) {
+                                          const X16SaveStage<PREC>* sv = nullptr, const short relu_lo = 0,
+                                          const unsigned bias_lds = 0 /* SAVE: LDS address of this stage's bias slot + 4 c */) {
     typedef typename X16<PREC>::frag frag;
     static_assert(!SAVE || NB == 1, "the training forward runs one block per wave");
     const int h = lane >> 5, c = lane & 31;
     float red[NB][32];
     unsigned gate_word = 0;
     const frag ones = X16<PREC>::ones_frag();
-    float bias_cur = bias[c];
+    float bias_cur = 0.0f, bias_nxt = 0.0f;
+    constexpr bool LB = SAVE && X16_SAVE_LDS_BIAS;
+    if constexpr (LB) {
+        x16_bias_read<0>(bias_cur, bias_lds);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bias_cur));  // once per stage; the tiles' values travel a tile ahead
+    } else {
+        bias_cur = bias[c];
+    }
     constexpr bool PACKS = (MODE == MODE_HIDDEN || MODE == MODE_LINEAR);
     f32x16 acc[1][NB];
     auto finish_half = [&](const int t, const int half) {  // registers 8*half .. 8*half+7 of tile t -> k-step 2t+half
@@ -69,7 +106,11 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
             // acc = bias, broadcast over the samples, by ONE extra MFMA (hi/lo split keeps ~16 mantissa bits):
             // lane r of the lower half holds bias[ot*32 + r], fetched one tile ahead
             const frag bf = X16<PREC>::bias_frag(bias_cur, h == 0);
-            if (ot + 1 < NT) bias_cur = bias[(ot + 1) * 32 + c];
+            if constexpr (LB) {
+                if constexpr (ot + 1 < NT) x16_bias_read<(ot + 1) * 128>(bias_nxt, bias_lds);
+            } else {
+                if (ot + 1 < NT) bias_cur = bias[(ot + 1) * 32 + c];
+            }
             f32x16 zero;
 #pragma unroll
             for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
@@ -93,13 +134,22 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
                 acc[cur][nb] = X16<PREC>::mfma(a_cur, b, acc[cur][nb]);
             }
         });
+        if constexpr (LB && ot + 1 < NT) {
+            asm volatile("" : "+v"(bias_nxt));  // landed: it is older than every fragment read awaited in the k-loop above
+            bias_cur = bias_nxt;
+        }
         X16_T(const unsigned long long s2 = x16_now();)
         if (PACKS) {
             finish_half(ot, 0);
             finish_half(ot, 1);
         }
         if constexpr (SAVE && PACKS) {
-            if (sv->tile0) x16_transpose_store<PREC>(hout[0][2 * ot], hout[0][2 * ot + 1], sv->I0, sv->I1, sv->tile0 + ot * 2 * X16_PIECE);
+            // (unconditional -- dead waves write a dump record -- and reported: the stream's rendezvous waits are counted)
+#ifndef X16_DIAG_NOIMG
+            x16_image_store<PREC>(hout[0][2 * ot], hout[0][2 * ot + 1], sv->tile0 + ot * 2 * X16_PIECE);
+            ws.note_stores(2);
+#endif
+#ifndef X16_DIAG_NOGATE
             // ReLU gates of the backward chain: bit 8*half + j of this tile's half-word = "stored activation > 0" of accumulator
             // register 8*half + j (same lane, same tile, same register in nerf_bwd_x16_kernel); two tiles share a 32-bit word
             unsigned m = 0;
@@ -112,10 +162,12 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
             // (v_pk_min_u16 + v_dot2_u32_u16 per packed pair would be 16 operations per tile instead of ~48, but hipcc expands
             // the packed min into compares and selects anyway and the dot2 result came out wrong on gfx950: not used)
             if constexpr (ot & 1) {
-                if (sv->gate0) sv->gate0[(ot >> 1) * 64] = gate_word | (m << 16);
+                __builtin_nontemporal_store(gate_word | (m << 16), sv->gate0 + (ot >> 1) * 64);
+                ws.note_stores(1);
             } else {
                 gate_word = m;
             }
+#endif
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -126,15 +178,14 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
 #pragma unroll
                 for (int r = 0; r < 16; ++r) red[nb][(ot & 1) * 16 + r] = fmaxf(acc[cur][nb][r], 0.0f) * aux[nb];
                 if constexpr (SAVE) {
-                    if (sv->tile0) {
 #pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            float v[8];
+                    for (int half = 0; half < 2; ++half) {
+                        float v[8];
 #pragma unroll
-                            for (int r = 0; r < 8; ++r) v[r] = fmaxf(acc[cur][nb][8 * half + r], 0.0f);
-                            *reinterpret_cast<frag*>(sv->tile0 + (2 * ot + half) * X16_PIECE) = X16<PREC>::pack(v);
-                        }
+                        for (int r = 0; r < 8; ++r) v[r] = fmaxf(acc[cur][nb][8 * half + r], 0.0f);
+                        __builtin_nontemporal_store(X16<PREC>::pack(v), reinterpret_cast<frag*>(sv->tile0 + (2 * ot + half) * X16_PIECE));
                     }
+                    ws.note_stores(2);
                 }
                 if (ot & 1) {
                     float s = butterfly32(red[nb], c);
@@ -155,7 +206,7 @@ __device__ __forceinline__ void x16_stage(WeightStream<PREC, WAVES>& ws, const f
 }
 
 // What the training forward leaves in HBM per 32-sample block (bf16 fused training path, train_x16.hip):
-//   xT   X16_XT_TILES tiles of 2 KiB: PE (2 tiles) | H0 .. H7 (12 tiles each), lane = channel pieces
+//   xT   X16_XT_TILES tiles of 2 KiB: PE (2 tiles) | H0 .. H7 (12 tiles each), [sample][channel] images (x16_core.h)
 //   gS   12 lane = sample fragments of relu(RGB_layer_1)
 //   geo  density pre-activation [32] | plane distance [32]
 //   gates  8 layers x 6 words x 64 lanes: the sign bits of H0 .. H7 in accumulator order (the dX chain's ReLU gates)
@@ -176,8 +227,10 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
     const int lane = threadIdx.x & 63;
     const int c = lane & 31, h = lane >> 5;
 
-    WeightStream<PREC, WAVES> ws;
-    ws.gsrc = packed + (size_t)wave * WeightStream<PREC, WAVES>::PPW * X16_PIECE + lane * 16;
+    // (the training forward keeps two fragments in flight instead of three: its saved-tile bookkeeping needs the registers)
+    typedef WeightStream<PREC, WAVES, X16_NCHUNK, X16_NBUF, SAVE ? X16_SAVE_DEPTH : X16_DEPTH> WS;
+    WS ws;
+    ws.gsrc = packed + (size_t)wave * WS::PPW * X16_PIECE + lane * 16;
     ws.ring = lds;
     ws.lds_addr0 = (unsigned)(size_t)(LDS_AS unsigned char*)lds + lane * 16;
     ws.wave = wave;
@@ -227,24 +280,39 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
     }
     const float* fb = fold + (size_t)__builtin_amdgcn_readfirstlane(frame) * N3DT_FOLD_STRIDE;
     X16SaveStage<PREC> svs;
-    unsigned char* xT_blk = nullptr;  // this block's xT tiles (+ lane * 16); nullptr on a dead block
+    unsigned char* xT_blk = nullptr;  // this block's xT tiles (+ the lane's image offset)
+    // record of this block in the saved buffers; a dead wave writes the dump record behind the last block (every wave must
+    // issue the stores the stream's counted waits are told about, x16_core.h)
+    const long rec = live[0] ? blk[0] : total_blocks;
     if constexpr (SAVE) {
-        svs.I0 = x16_ident_frag<PREC>(0, lane);
-        svs.I1 = x16_ident_frag<PREC>(1, lane);
-        if (live[0]) {
-            xT_blk = tsv.xT + (size_t)blk[0] * X16_XT_TILES * 2 * X16_PIECE + lane * 16;
-            x16_transpose_store<PREC>(pe[0][0], pe[0][1], svs.I0, svs.I1, xT_blk);
-            x16_transpose_store<PREC>(pe[0][2], pe[0][3], svs.I0, svs.I1, xT_blk + 2 * X16_PIECE);
-        }
+        xT_blk = tsv.xT + (size_t)rec * X16_XT_TILES * 2 * X16_PIECE + x16_image_lane_offset(lane);
+        x16_image_store<PREC>(pe[0][0], pe[0][1], xT_blk);
+        x16_image_store<PREC>(pe[0][2], pe[0][3], xT_blk + 2 * X16_PIECE);
     }
     // output tile 0 of hidden layer l inside the block's xT record
     auto sv_hidden = [&](const int l) -> const X16SaveStage<PREC>* {
         if constexpr (SAVE) {
-            svs.tile0 = xT_blk ? xT_blk + (size_t)(2 + 12 * l) * 2 * X16_PIECE : nullptr;
-            svs.gate0 = xT_blk ? tsv.gates + ((size_t)blk[0] * 8 + l) * 6 * 64 + lane : nullptr;
+            svs.tile0 = xT_blk + (size_t)(2 + 12 * l) * 2 * X16_PIECE;
+            svs.gate0 = tsv.gates + ((size_t)rec * 8 + l) * 6 * 64 + lane;
             return &svs;
         } else {
             return nullptr;
+        }
+    };
+    // SAVE: per-wave bias slots in LDS, filled a stage ahead (X16BiasLds above); stage k reads slot k & 1
+    X16BiasLds bl;
+    if constexpr (SAVE && X16_SAVE_LDS_BIAS) {
+        bl.slots = lds + X16_NBUF * X16_CH * X16_PIECE + (size_t)WAVES * NB * 4 * X16_PIECE + (size_t)wave * 2 * X16_BIAS_SLOT;
+        bl.addr = (unsigned)(size_t)(LDS_AS unsigned char*)bl.slots + 4 * c;
+        bl.stage_in(fb + n3dt_bias_offset(0), 384, 0, lane);
+    }
+    // the bias slot of SAVE stage number k (0 .. 8), after staging the table of the stage that follows it
+    auto bias_slot = [&](const int k, const int next_table, const int next_n) -> unsigned {
+        if constexpr (SAVE && X16_SAVE_LDS_BIAS) {
+            if (next_table >= 0) bl.stage_in(fb + n3dt_bias_offset(next_table), next_n, (k + 1) & 1, lane);
+            return bl.addr + (k & 1) * X16_BIAS_SLOT;
+        } else {
+            return 0u;
         }
     };
     ws.prologue_wait();
@@ -253,17 +321,17 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
     frag ha[NB][24], hb[NB][24];
     float aux[NB];
     // FeaExt_module_0 (reference: NetWorks/models.py:69-71)
-    x16_stage<PREC, NB, WAVES, 4, 4, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(0), pe, nullptr, ha, ha, aux, po, live, lane, sv_hidden(0));
+    x16_stage<PREC, NB, WAVES, 4, 4, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(0), pe, nullptr, ha, ha, aux, po, live, lane, sv_hidden(0), 0, bias_slot(0, 1, 384));
     // FeaExt_module_1..7 with the skip concat after layer 4 (models.py:72-76).  Fully unrolled on purpose: rolling the
     // identical 384->384 layers into a loop (tried: one-layer body + register copy, two-layer ping-pong body) makes the
     // register allocator spill 120-270 VGPRs across the back edge and runs 1.7x slower.
-    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(1), pe, nullptr, ha, hb, aux, po, live, lane, sv_hidden(1));
-    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(2), pe, nullptr, hb, ha, aux, po, live, lane, sv_hidden(2));
-    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(3), pe, nullptr, ha, hb, aux, po, live, lane, sv_hidden(3));
-    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(4), pe, nullptr, hb, ha, aux, po, live, lane, sv_hidden(4));
-    x16_stage<PREC, NB, WAVES, 28, 4, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(5), pe, pe_lds, ha, hb, aux, po, live, lane, sv_hidden(5));
-    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(6), pe, nullptr, hb, ha, aux, po, live, lane, sv_hidden(6));
-    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(7), pe, nullptr, ha, hb, aux, po, live, lane, sv_hidden(7));
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(1), pe, nullptr, ha, hb, aux, po, live, lane, sv_hidden(1), 0, bias_slot(1, 2, 384));
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(2), pe, nullptr, hb, ha, aux, po, live, lane, sv_hidden(2), 0, bias_slot(2, 3, 384));
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(3), pe, nullptr, ha, hb, aux, po, live, lane, sv_hidden(3), 0, bias_slot(3, 4, 384));
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(4), pe, nullptr, hb, ha, aux, po, live, lane, sv_hidden(4), 0, bias_slot(4, 5, 384));
+    x16_stage<PREC, NB, WAVES, 28, 4, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(5), pe, pe_lds, ha, hb, aux, po, live, lane, sv_hidden(5), 0, bias_slot(5, 6, 384));
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(6), pe, nullptr, hb, ha, aux, po, live, lane, sv_hidden(6), 0, bias_slot(6, 7, 384));
+    x16_stage<PREC, NB, WAVES, 24, 0, 12, MODE_HIDDEN, SAVE>(ws, fb + n3dt_bias_offset(7), pe, nullptr, ha, hb, aux, po, live, lane, sv_hidden(7), 0, bias_slot(7, 10, 192));
     // density head on h7 (models.py:78,84); the bias rides in the accumulator
     x16_stage<PREC, NB, WAVES, 24, 0, 1, MODE_DENSITY, false>(ws, fb + n3dt_bias_offset(8), pe, nullptr, hb, ha, aux, po, live, lane);
     // alpha, in-block transmittance and weights (reference: NetWorks/utils.py:273-289)
@@ -302,11 +370,11 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
     // RGB_layer_0 -> RGB_layer_1 as ONE merged 192 x 384 layer on h7 (no activation sits between them, models.py:79-81;
     // merged matrix and bias built by pack / fold), relu, weighted by the sample weights and reduced over the samples
     if constexpr (SAVE) {
-        svs.tile0 = live[0] ? tsv.gS + (size_t)blk[0] * 12 * X16_PIECE + lane * 16 : nullptr;
+        svs.tile0 = tsv.gS + (size_t)rec * 12 * X16_PIECE + lane * 16;
         svs.gate0 = nullptr;
     }
     x16_stage<PREC, NB, WAVES, 24, 0, 6, MODE_COMPOSITE, SAVE>(ws, fb + n3dt_bias_offset(10), pe, nullptr, hb, ha, aux, po, live, lane,
-                                                                     SAVE ? &svs : nullptr);
+                                                                     SAVE ? &svs : nullptr, 0, bias_slot(8, -1, 0));
 #ifdef X16_STAMP
     if (wlocal && lane == 0 && live[0]) {
         float* dbg = wlocal + (size_t)blk[0] * X16_BS;
@@ -350,7 +418,7 @@ extern "C" void n3dt_launch_nerf_fwd_x16_train(const N3dtGeom* g, const void* pa
     const int bpr = (g->n_samples + X16_BS - 1) / X16_BS;
     const long total = (long)g->batch * g->n_rays * bpr;
     const int grid = (int)((total + WAVES - 1) / WAVES);
-    const size_t lds_bytes = X16_NBUF * X16_CH * X16_PIECE + (size_t)WAVES * 4 * X16_PIECE;
+    const size_t lds_bytes = X16_NBUF * X16_CH * X16_PIECE + (size_t)WAVES * 4 * X16_PIECE + (size_t)WAVES * 2 * X16_BIAS_SLOT;
     auto kern = nerf_fwd_x16_train_kernel<WAVES>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     X16TrainSave tsv{reinterpret_cast<unsigned char*>(xT), reinterpret_cast<unsigned char*>(gS), geo, reinterpret_cast<unsigned*>(gates)};

@@ -180,7 +180,14 @@ __device__ __forceinline__ void x16_pin_v(T*& p) {  // per-lane pointers
     p = (T*)(GLOBAL_AS T*)v;
 }
 
-template <int PREC, int WAVES, int NCHUNK = X16_NCHUNK, int NBUF = X16_NBUF>
+#ifndef X16_RV_RAW
+#define X16_RV_RAW 0
+#endif
+#ifndef X16_NT_STORE
+#define X16_NT_STORE 1  // saved tiles are streamed (written once, read by a later kernel): nontemporal stores (fwd 1.65 -> 1.35 ms)
+#endif
+// DEPTH: fragments in flight per wave (DEPTH; the training forward runs with 2 to stay inside its register budget)
+template <int PREC, int WAVES, int NCHUNK = X16_NCHUNK, int NBUF = X16_NBUF, int DEPTH = X16_DEPTH>
 struct WeightStream {
     X16_T(unsigned long long t_rv = 0; unsigned long long t_mfma = 0; unsigned long long t_epi = 0; unsigned long long t_bias = 0;
           int tile_no = 0; float* tl = nullptr;)
@@ -199,7 +206,7 @@ struct WeightStream {
     // (9.8 ms) -- the one-tile kernel sits at 254 of 256 registers and the loop adds a handful.  Results were correct.
     int limit;                  // chunks to stage in all: passes * NCHUNK
     int src_c;                  // source chunk of the next issue (wraps at NCHUNK: every pass streams the same weights)
-    frag a[X16_DEPTH];          // piece p sits in a[p % X16_DEPTH]
+    frag a[DEPTH];          // piece p sits in a[p % DEPTH]
     static constexpr int PPW = X16_CH / WAVES;  // pieces each wave stages per chunk
 
     __device__ __forceinline__ void issue(int c) {  // c: chunk count since the prologue (picks the ring buffer)
@@ -227,28 +234,57 @@ struct WeightStream {
         __syncthreads();
         chunk = 0;
         meets = 0;
+        vm_cur = 0;
+        vm_prev = 0;
         cur_addr = lds_addr0;
         nxt_addr = lds_addr0 + X16_CHUNK_BYTES;
         preload<0>();
     }
     template <int J>
     __device__ __forceinline__ void preload() {
-        if constexpr (J < X16_DEPTH - 1) {
+        if constexpr (J < DEPTH - 1) {
             read_frag<J * X16_PIECE>(a[J], cur_addr);
             preload<J + 1>();
         }
     }
-    // NBUF > 3 (a deeper ring: chunk meets+1 was issued NBUF-2 rendezvous ago) only needs the loads OLDER than the
-    // newest (NBUF-3) chunks to have landed: loads return in order, so "at most (NBUF-3)*PPW operations outstanding"
-    // is enough (stores in the count only make the wait more conservative) -- while newer chunks are in flight behind
-    // it, i.e. until the stream's tail.
+    // The wait of a rendezvous is COUNTED.  Chunk meets+1 was issued NBUF-2 rendezvous ago; vector-memory operations retire in
+    // order (loads and stores share vmcnt on gfx9-family parts), so "at most K operations outstanding", K = what this wave has
+    // issued SINCE that chunk's loads, means they have landed.  K = the (NBUF-3) newer chunks' loads plus the stores the kernel
+    // reports through note_stores() -- the training kernels write 2-3 KiB per tile, and with a plain vmcnt(0) every rendezvous
+    // also waited for the acknowledgement of the stores issued a tile ago (the write path runs near the HBM write bandwidth
+    // there: the forward with SAVE took 1.58 ms against 0.92 ms without).  Safety: K must never exceed the true count, so only
+    // stores that are issued UNCONDITIONALLY at their program point may be reported (dead waves write a dump record); loads and
+    // stores the kernel does not report only make the wait stricter.  All of this folds at compile time (straight-line code).
+    // The rendezvous itself is a raw s_barrier between compiler barriers: __syncthreads() carries a workgroup-scope release
+    // fence, for which hipcc emits s_waitcnt vmcnt(0) lgkmcnt(0) -- every store and every fragment prefetch in flight.  What the
+    // barrier orders here needs neither: this wave's pieces of chunk meets+1 are awaited just above, and a wave's reads of chunk
+    // meets-1 (whose buffer is overwritten next) were consumed by MFMAs a chunk ago.
+    int vm_cur = 0, vm_prev = 0;  // reported stores since the last rendezvous / in the period before it
+    __device__ __forceinline__ void note_stores(const int n) { vm_cur += n; }
+    template <int K>
+    __device__ __forceinline__ static void wait_vm() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(K) : "memory");
+    }
     __device__ __forceinline__ void rendezvous() {
-        if (NBUF > 3 && meets + NBUF - 2 < limit) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NBUF - 3) * PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk meets+1 have landed
-        __syncthreads();                                                          // everyone's have; everyone has left chunk meets-1
+        int newer = limit - 2 - meets;  // chunks issued after chunk meets+1: meets+2 .. min(limit-1, meets+NBUF-2)
+        newer = newer < 0 ? 0 : (newer > NBUF - 3 ? NBUF - 3 : newer);
+        int k = newer * PPW + vm_cur + (NBUF > 3 ? vm_prev : 0);
+        if (k > 15) k = 15;
+        static_for<0, 16>([&](auto k_c) {
+            constexpr int K = decltype(k_c)::value;
+            if (k == K) wait_vm<K>();  // this wave's pieces of chunk meets+1 have landed
+        });
+#if X16_RV_RAW
+        __builtin_amdgcn_s_barrier();  // everyone's have; everyone has left chunk meets-1
+        asm volatile("" ::: "memory");
+#else
+        __syncthreads();
+#endif
 #ifndef X16_NODMA  // diagnostic build: the stream stops after the prologue (results are garbage, the timing is the point)
         if (meets + NBUF - 1 < limit) issue(meets + NBUF - 1);
 #endif
+        vm_prev = vm_cur;
+        vm_cur = 0;
         ++meets;
     }
     // The fragment reads are issued from inline asm so that their completion can be awaited with a COUNTED
@@ -261,33 +297,33 @@ struct WeightStream {
     __device__ __forceinline__ void read_frag(frag& dst, const unsigned addr) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
     }
-    template <int YOUNGER = X16_DEPTH - 1>  // fragment reads issued after this one that may still be in flight
+    template <int YOUNGER = DEPTH - 1>  // fragment reads issued after this one that may still be in flight
     __device__ __forceinline__ void await_frag(frag& f) {
         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "i"(YOUNGER));
     }
-    // Fragment of stage-local piece P (stages are whole chunks, so P % X16_CH and P % X16_DEPTH equal their
+    // Fragment of stage-local piece P (stages are whole chunks, so P % X16_CH and P % DEPTH equal their
     // stream-global values).  LAST/NP: the final stage must not prefetch past the end of the stream.
     template <bool LAST, int NP, int P>
     __device__ __forceinline__ frag next() {
-        constexpr int rv = X16_CH - X16_DEPTH;
+        constexpr int rv = X16_CH - DEPTH;
         if (P % X16_CH == rv) {
             X16_T(const unsigned long long r0 = x16_now();)
             rendezvous();
             X16_T(t_rv += x16_now() - r0;)
         }
-        constexpr int Q = P + X16_DEPTH - 1;
+        constexpr int Q = P + DEPTH - 1;
 #ifdef X16_NOLDS  // diagnostic build: no fragment reads at all (garbage results)
         if ((P + 1) % X16_CH == 0) ++chunk;
         return a[0];
 #endif
         if (!(LAST && Q >= NP)) {
             const unsigned addr = (Q % X16_CH < P % X16_CH) ? nxt_addr : cur_addr;
-            read_frag<(Q % X16_CH) * X16_PIECE>(a[Q % X16_DEPTH], addr);
+            read_frag<(Q % X16_CH) * X16_PIECE>(a[Q % DEPTH], addr);
         }
         // at the stream's tail fewer reads are in flight behind this one: the count shrinks with them
-        constexpr int younger = (LAST && NP - 1 - P < X16_DEPTH - 1) ? NP - 1 - P : X16_DEPTH - 1;
-        await_frag<younger>(a[P % X16_DEPTH]);
-        const frag r = a[P % X16_DEPTH];
+        constexpr int younger = (LAST && NP - 1 - P < DEPTH - 1) ? NP - 1 - P : DEPTH - 1;
+        await_frag<younger>(a[P % DEPTH]);
+        const frag r = a[P % DEPTH];
         if ((P + 1) % X16_CH == 0) {
             ++chunk;
             cur_addr = nxt_addr;
@@ -305,7 +341,7 @@ struct WeightStream {
     __device__ __forceinline__ void settle() {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]));
 #pragma unroll
-        for (int i = 1; i < X16_DEPTH; ++i) asm volatile("" : "+v"(a[i]));  // every slot stays reserved up to the wait
+        for (int i = 1; i < DEPTH; ++i) asm volatile("" : "+v"(a[i]));  // every slot stays reserved up to the wait
     }
 };
 
@@ -349,48 +385,65 @@ __device__ __forceinline__ float butterfly32(float (&v)[32], const int c) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Transposing a packed tile with the matrix pipe (training path).
+// Saved tiles of the training path: a [sample][channel] image that the weight-gradient kernel reads TRANSPOSED.
 //
 // A 32x32 tile in "lane = sample" form is two fragments f0, f1: lane (c, h) element j of f_s holds
 // X[channel 16s + 8(j>>2) + 4h + (j&3)][sample c] (the B-operand form the fused kernels keep activations in).
-// Taken as the A operand against the selection fragments I_0, I_1 below, two MFMAs return X^T in accumulator
-// layout (lane = channel, registers = samples); packed, that is the tile in "lane = channel" form, two 1 KiB
-// pieces P_0, P_1: lane (r, h) element j of P_s holds X[channel r][sample 16s + 8(j>>2) + 4h + (j&3)] -- the
-// operand form of a product that sums over SAMPLES (the weight gradients dW = dZ^T X), with the same sample
-// permutation for every tensor.  The same two selection fragments turn pieces back into an accumulator-layout
-// tile (lane = sample) -- used for the ReLU gates of the backward chain.  Exact: x * 1.0 summed with zeros.
+// The weight gradients dW = dZ^T X sum over SAMPLES, so their MFMA operands need "lane = channel" fragments (8 samples of
+// one channel per lane).  The first version transposed every tile on the matrix pipe before storing it (two selection MFMAs,
+// 8 v_cvt_pk, the MFMA -> VALU latency: 8 % more MFMAs in the training forward and in the dX chain).  gfx950 transposes on
+// the way OUT of LDS instead (ds_read_b64_tr_b16), so the producers now store their fragments as they are:
+//     tile image (2 KiB) = [32 samples][32 channels] 16-bit, 64-byte rows;  lane (c, h) writes f_s at 64 c + 32 s + 16 h
+// (row c = [ch 0-3, 8-11, 4-7, 12-15 | ch 16-19, 24-27, 20-23, 28-31]).  dw_x16_body moves the image to LDS as it is (two 1 KiB
+// LDS-DMA pieces) and reads it with x16_tr_frag below.
 // ---------------------------------------------------------------------------------------------
+// dst: per-lane pointer = tile + 64 * (lane & 31) + 16 * (lane >> 5)   (x16_image_lane_offset)
+__device__ __forceinline__ int x16_image_lane_offset(const int lane) { return 64 * (lane & 31) + 16 * (lane >> 5); }
 template <int PREC>
-__device__ __forceinline__ typename X16<PREC>::frag x16_ident_frag(const int s, const int lane) {
-    const int c = lane & 31, h = lane >> 5;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (c == 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) ? 1.0f : 0.0f;
-    return X16<PREC>::pack(v);
-}
-
-template <int PREC>
-__device__ __forceinline__ f32x16 x16_transpose_tile(const typename X16<PREC>::frag f0, const typename X16<PREC>::frag f1,
-                                                     const typename X16<PREC>::frag I0, const typename X16<PREC>::frag I1) {
-    f32x16 z;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-    z = X16<PREC>::mfma(f0, I0, z);
-    return X16<PREC>::mfma(f1, I1, z);
-}
-
-// lane = sample tile (f0, f1) -> two lane = channel pieces at dst (per-lane pointer, lane * 16 included), 1 KiB apart
-template <int PREC>
-__device__ __forceinline__ void x16_transpose_store(const typename X16<PREC>::frag f0, const typename X16<PREC>::frag f1,
-                                                    const typename X16<PREC>::frag I0, const typename X16<PREC>::frag I1,
-                                                    unsigned char* dst) {
+__device__ __forceinline__ void x16_image_store(const typename X16<PREC>::frag f0, const typename X16<PREC>::frag f1, unsigned char* dst) {
     typedef typename X16<PREC>::frag frag;
-    const f32x16 t = x16_transpose_tile<PREC>(f0, f1, I0, I1);
-    float v[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = t[r];
-    *reinterpret_cast<frag*>(dst) = X16<PREC>::pack(v);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = t[8 + r];
-    *reinterpret_cast<frag*>(dst + X16_PIECE) = X16<PREC>::pack(v);
+#if X16_NT_STORE
+    __builtin_nontemporal_store(f0, reinterpret_cast<frag*>(dst));
+    __builtin_nontemporal_store(f1, reinterpret_cast<frag*>(dst + 32));
+#else
+    *reinterpret_cast<frag*>(dst) = f0;
+    *reinterpret_cast<frag*>(dst + 32) = f1;
+#endif
 }
+// Per-lane LDS byte offset of the transposed reads inside a tile image: lane (r, h) of the 32x32x16 operand takes channel r,
+// samples 16 s' + 8 h + 0..7 as two 4-sample blocks.  In a group of 16 lanes, lane 4q + p supplies the address of sample row q,
+// channels 4p .. 4p+3 of the group's 16 (the 8-byte unit (p & 1) * 2 + (p >> 1) of the row's 32 bytes).  A 32-lane half covers
+// 4 rows x 64 bytes = all 64 banks once: conflict-free.  Checked against exact integer data on the GPU (tools/tr_probe.hip).
+__device__ __forceinline__ unsigned x16_tr_lane_offset(const int lane) {
+    const int r = lane & 31, h = lane >> 5, q = (r & 15) >> 2, p = r & 3;
+    return 64u * (8 * h + q) + 32u * (r >> 4) + 8u * ((p & 1) * 2 + (p >> 1));
+}
+// The reads are issued from inline asm (x16_tr_issue) and retired by ONE s_waitcnt (x16_tr_settle) that names every destination:
+// through the builtin hipcc orders them behind the LDS-DMA stream in flight (s_waitcnt vmcnt(0) in front of the first read of
+// every stage -- the stages still loading are then waited for as well, and the pipeline is one stage deep).
+typedef unsigned x16_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned x16_u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void x16_tr_issue(x16_u32x2& d, const unsigned lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(lds_addr), "i"(OFF) : "memory");
+}
+// four 64-bit reads = the two k-steps of one 32 x 32 tile image at LDS byte address tile_lane (x16_tr_lane_offset included)
+struct X16TrTile {
+    x16_u32x2 q[4];  // k-step sp: q[2 sp] (samples +0..3), q[2 sp + 1] (samples +4..7)
+    template <int TILE_OFF>
+    __device__ __forceinline__ void issue(const unsigned tile_lane) {
+        x16_tr_issue<TILE_OFF>(q[0], tile_lane);
+        x16_tr_issue<TILE_OFF + 256>(q[1], tile_lane);
+        x16_tr_issue<TILE_OFF + 1024>(q[2], tile_lane);
+        x16_tr_issue<TILE_OFF + 1280>(q[3], tile_lane);
+    }
+    __device__ __forceinline__ void pin() {  // the destinations stay reserved up to the wait (x16_tr_settle)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(q[i]));
+    }
+    __device__ __forceinline__ bf16x8 frag(const int sp) const {
+        const x16_u32x4 v = {q[2 * sp][0], q[2 * sp][1], q[2 * sp + 1][0], q[2 * sp + 1][1]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+};
+__device__ __forceinline__ void x16_tr_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }

@@ -22,6 +22,6 @@ for r in range(rounds):
             print(l, "FAILED", out.stderr[-400:])
             continue
         d = json.loads(line[-1])
-        res[l].append((d["ms_per_step"], d["roofline"]["avg_launch_ms"]))
+        res[l].append((d["ms_per_step"], (d.get("roofline") or {}).get("avg_launch_ms", float("nan"))))
 for l in libs:
     print("%-60s ms/step %s | kernel ms %s" % (l, " ".join("%.3f" % a for a, _ in res[l]), " ".join("%.3f" % b for _, b in res[l])))
