@@ -1,0 +1,100 @@
+"""Randomised check of the fused mixed-precision training path (nerf_fwd_x16_train / nerf_bwd_x16 / dw_x16 kernels) against the
+exact-fp32 training path on the same inputs (GPU; both paths go through the C ABI).
+
+usage: fuzz_train.py [cases=40] [seed=1]
+Draws featmap sizes (incl. ones whose block count leaves dead waves in the last workgroup: the saved-tile dump record), sample
+counts with ragged last blocks, batch sizes, the gaze / audio-less module variants and, for a third of the cases, camera
+gradients.  Band asserted: per tensor max error <= 15 % of the tensor's scale and cosine >= 0.99 (the seed-0 cases of
+tests/test_gpu_train.py sit at <= 1 % / >= 0.9989; over random weight seeds the first layers reach 12 % / 0.996).  Camera
+gradients are REPORTED, not asserted: their 2^k-weighted cancellation over a few hundred samples makes the bf16 path's d R / d T
+a direction of varying quality on tiny geometries (cosine 0.75 - 1.0 seen), which is why train_precision="fp32" is the
+documented mode for fitting."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "nerf-3dtalker-code_amd"))
+
+
+def variant_kw(variant):
+    return {"include_gaze": True, "eye_gaze_dim": 64} if variant == "gaze" else ({"audio_dim": 0} if variant == "noaudio" else {})
+
+
+def grads(opt, sd, B, precision, t_rand, cam, variant, dev):
+    from n3dt import HeadNeRFNet, synthetic as syn
+    from n3dt.train import data_losses, disk_mask
+    kw = variant_kw(variant)
+    net = HeadNeRFNet(opt, False, False, train_precision=precision, **kw).to(dev)
+    net.load_state_dict(sd)
+    net.neural_render.train_precision = "fp32"  # isolate the volumetric stage
+    d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in syn.frame_inputs(opt, B, **kw).items()}
+    names = ["audiostyle", "shape_code", "appea_code"] + (["batch_Rmats", "batch_Tvecs"] if cam else [])
+    if variant == "noaudio":
+        names.remove("audiostyle")
+    for k in names:
+        d[k] = d[k].clone().requires_grad_(True)
+    out = net("train", d["batch_xy"], d["batch_uv"], d.get("audiostyle"), None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+              d["batch_Tvecs"], d["batch_inv_inmats"], t_rand=t_rand)["coarse_dict"]
+    terms = data_losses(out, torch.full_like(out["merge_img"], 0.5), disk_mask(B, opt.pred_img_size).to(dev))
+    (terms["bg_loss"] + terms["head_loss"] + terms["nonhead_loss"]).backward()
+    g = {k: d[k].grad.detach().clone() for k in names}
+    g.update({n: p.grad.detach().clone() for n, p in net.named_parameters() if n.startswith("fg_CD_predictor")})
+    return out["merge_img"].detach(), g
+
+
+def main():
+    from n3dt import BaseOptions, synthetic as syn
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    bad = 0
+    worst = {"max": 0.0, "cos": 1.0, "cam_cos": 1.0}
+    for case in range(cases):
+        fs = int(rng.choice([4, 6, 8, 10, 12, 16, 20]))
+        ns = int(rng.choice([3, 16, 20, 31, 32, 33, 40, 64, 65, 96, 100]))
+        B = int(rng.choice([1, 2, 3, 5]))
+        variant = str(rng.choice(["plain", "plain", "gaze", "noaudio"]))
+        cam = bool(rng.random() < 0.33)
+        opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": fs * 4, "num_sample_coarse": ns})
+        kw = variant_kw(variant)
+        sd = syn.make_state_dict(opt, seed=int(rng.integers(0, 1000)), bg_noise=0.1, **kw)
+        t_rand = syn.stratified_noise(B, fs * fs, ns, int(rng.integers(0, 1000))).to(dev)
+        img32, g32 = grads(opt, sd, B, "fp32", t_rand, cam, variant, dev)
+        img16, g16 = grads(opt, sd, B, "bf16", t_rand, cam, variant, dev)
+        blocks = B * fs * fs * ((ns + 31) // 32)
+        msg = []
+        if float((img32 - img16).abs().max()) > 4e-3:
+            msg.append("image %.2e" % float((img32 - img16).abs().max()))
+        for k in g32:
+            a, b = g32[k].double().flatten(), g16[k].double().flatten()
+            scale = float(a.abs().max())
+            if scale == 0.0 and float(b.abs().max()) == 0.0:
+                continue
+            err = float((a - b).abs().max()) / (scale + 1e-30)
+            cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+            camk = k in ("batch_Rmats", "batch_Tvecs")
+            if camk:
+                worst["cam_cos"] = min(worst["cam_cos"], cos)
+                continue
+            worst["max"] = max(worst["max"], err)
+            worst["cos"] = min(worst["cos"], cos)
+            if err > 0.15 or cos < 0.99:
+                msg.append("%s err %.3f cos %.5f" % (k, err, cos))
+        tag = "fs %2d ns %3d B %d %-7s cam %d blocks %5d (%%8 = %d)" % (fs, ns, B, variant, cam, blocks, blocks % 8)
+        if msg:
+            bad += 1
+            print("FAIL", tag, "; ".join(msg[:4]))
+        else:
+            print("ok  ", tag)
+        sys.stdout.flush()
+    print("%d / %d cases failed; worst non-camera tensor: max error %.3f of scale, cosine %.5f; worst camera-gradient cosine %.3f" %
+          (bad, cases, worst["max"], worst["cos"], worst["cam_cos"]))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
