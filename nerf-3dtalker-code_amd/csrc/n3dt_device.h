@@ -140,6 +140,17 @@ __device__ __forceinline__ int n3dt_rem(const size_t x, const N3dtDiv v) { retur
 // Slots whose input index falls off the axis keep weight 0.  (Evaluating the nine bilinear samples separately costs 36 loads
 // per output pixel; this is 9.)
 __device__ __forceinline__ void n3dt_up_blur_w3(const int o, const int n, float (&w3)[3]) {
+    if (n >= 3) {
+        // The loop below in closed form (every weight is a dyadic fraction, so this is bit-identical): interior outputs take
+        // [5, 10, 1] / 16 (even) or [1, 10, 5] / 16 (odd); only the two outputs at either end of the axis differ.  The loop costs
+        // ~60 VALU operations per call and the fused blur kernel calls it four times per thread: 28 of its 125 us.
+        const bool ev = (o & 1) == 0;
+        const bool first = o == 0, second = o == 1, last = o == 2 * n - 1, last2 = o == 2 * n - 2;
+        w3[0] = (first || second) ? 0.0f : (last ? 0.125f : (ev ? 0.3125f : 0.0625f));
+        w3[1] = (first || last) ? 0.875f : ((second || last2) ? 0.6875f : 0.625f);
+        w3[2] = (last || last2) ? 0.0f : (first ? 0.125f : (ev ? 0.0625f : 0.3125f));
+        return;
+    }
     const int base = o >> 1;
     w3[0] = w3[1] = w3[2] = 0.0f;
 #pragma unroll
