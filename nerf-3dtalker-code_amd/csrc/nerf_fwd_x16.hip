@@ -59,10 +59,6 @@ struct X16BiasLds {
                 __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(table + 64 * i + lane), (LDS_AS void*)(slots + slot * X16_BIAS_SLOT + 256 * i), 4, 0, 0);
     }
 };
-template <int OFF>
-__device__ __forceinline__ void x16_bias_read(float& dst, const unsigned addr) {
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
-}
 
 template <int PREC, int NB, int WAVES, int KS, int KPE, int NT, int MODE, bool SAVE = false, class WS>
 __device__ __forceinline__ void x16_stage(WS& ws, const float* __restrict__ bias,

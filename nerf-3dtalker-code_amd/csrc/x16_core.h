@@ -345,6 +345,13 @@ struct WeightStream {
     }
 };
 
+// one float from LDS, issued from inline asm and NOT awaited: LDS returns in order, so the value has landed once a fragment read
+// issued after it has been awaited (the caller then pins it with asm volatile("" : "+v"(dst)) before the first use)
+template <int OFF>
+__device__ __forceinline__ void x16_bias_read(float& dst, const unsigned addr) {
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
+}
+
 // positional-encoding channel `ch` (0..63) via v_sin_f32 on a two-term phase in revolutions.  The three
 // coordinates travel as separate scalars and are picked with selects: with float[3] arguments hipcc turned the
 // runtime `dim` into an index into a private-memory copy (28 B/lane of scratch, 117 MB of traffic per launch).
