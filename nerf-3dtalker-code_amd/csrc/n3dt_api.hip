@@ -320,6 +320,11 @@ static int neural_render_common(const N3dtGeom* g, int nb, int precision, const 
     if (g->n_blocks < 1 || g->n_blocks > N3DT_MAX_BLOCKS) return fail(N3DT_EINVAL, "n_blocks must be in 1..8");
     if (g->feat_nc != 256) return fail(N3DT_EINVAL, "only featmap_nc == 256 is built");
     if (g->featmap_size < 2) return fail(N3DT_EINVAL, "featmap_size < 2 (reflect border needs 2 pixels)");
+    {
+        // the kernels index one map level with 32-bit in-plane offsets: pixels x channels of the largest level below 2^31
+        const size_t side = (size_t)g->featmap_size << g->n_blocks, elems = (size_t)nb * side * side * 32;
+        if (elems >= ((size_t)1 << 31)) return fail(N3DT_EINVAL, "neural render: nb x output pixels x 32 channels must stay below 2^31 (split the batch)");
+    }
     if (workspace_bytes < n3dt_neural_render_workspace_bytes(g, nb)) return fail(N3DT_EWORKSPACE, "neural render workspace too small");
     for (int i = 0; i <= g->n_blocks; ++i)
         if (!p->to_rgb_w[i] || !p->to_rgb_b[i]) return fail(N3DT_EINVAL, "NULL feat_2_rgb parameter");
