@@ -182,6 +182,16 @@ class NeuralRenderer(nn.Module):
         then); without `ws` the module keeps one workspace per (nb, device, stream), which also holds its packed weights."""
         nb = featmap_hwc.shape[0]
         assert featmap_hwc.is_contiguous()
+        # the kernels index one map level with 32-bit offsets (nb x output pixels x 32 channels < 2^31: 255 maps at 512^2,
+        # 63 at 1024^2); a larger batch -- a long novel-view sweep -- goes through in slices
+        side = self.featmap_size << self.n_blocks
+        cap = getattr(self, "_max_maps_per_call", None) or max(1, ((1 << 31) - 1) // (side * side * 32))
+        if nb > cap:
+            assert ws is None, "a caller-owned workspace is sized for one call"
+            out = img if img is not None else torch.empty(nb, 3, side, side, dtype=torch.float32, device=featmap_hwc.device)
+            for i in range(0, nb, cap):
+                self.render_hwc(featmap_hwc[i:i + cap], precision, img=out[i:i + cap])
+            return out
         geom = self._geom(nb)
         if ws is None:
             dev = featmap_hwc.device

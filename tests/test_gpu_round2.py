@@ -477,3 +477,21 @@ def test_randomised_parity_sweep_against_the_oracle():
         assert mod.main() == 0
     finally:
         sys.argv = argv
+
+
+def test_oversized_renderer_batches_go_through_in_slices():
+    """NeuralRenderer.render_hwc slices a batch that the 32-bit level indexing of the kernels cannot take in one call (255 maps at
+    512^2); forced here with a cap of 2 maps per call: same images as the single call, bit for bit."""
+    from n3dt import BaseOptions, HeadNeRFNet
+    opt = BaseOptions({"featmap_size": 8, "featmap_nc": 256, "pred_img_size": 32, "num_sample_coarse": 8})
+    net = HeadNeRFNet(opt, False, False).to(dev())
+    nr = net.neural_render
+    maps = torch.randn(5, 8, 8, 256, generator=torch.Generator().manual_seed(3)).to(dev())
+    for prec in ("fp32", "bf16"):
+        whole = nr.render_hwc(maps, prec).clone()
+        nr._max_maps_per_call = 2
+        try:
+            sliced = nr.render_hwc(maps, prec)
+        finally:
+            nr._max_maps_per_call = None
+        assert torch.equal(whole, sliced), prec

@@ -40,6 +40,13 @@ def test_geometry_validation_without_a_gpu():
     blocks = 64 * 1
     assert L.n3dt_render_train_saved_bytes(ctypes.byref(g)) >= blocks * 98 * 2048
     assert L.n3dt_render_train_workspace_bytes(ctypes.byref(g)) >= blocks * 103 * 2048
+    # the 2-D renderer indexes a map level with 32-bit offsets: a batch whose largest level reaches 2^31 elements is refused
+    # before anything is launched (the host mirror slices such batches: NeuralRenderer.render_hwc)
+    big = ops.make_geom(1, 64 * 64, 64, 384, 256, 179, 127, 64, 64, 3, 2.5, -3.5)  # 64^2 -> 512^2
+    rp = _lib.RenderParams()
+    dummy = ctypes.c_void_p(256)
+    rc = L.n3dt_neural_render_fwd(ctypes.byref(big), 256, _lib.BF16, ctypes.byref(rp), dummy, dummy, dummy, ctypes.c_size_t(1 << 40), None)
+    assert rc == -1 and b"2^31" in L.n3dt_last_error()
 
 
 def test_state_dict_inventory_matches_reference_keys():
