@@ -190,7 +190,9 @@ int n3dt_composite(int batch, int n_rays, int n_samples, int channels, const flo
  * `precision` selects the arithmetic of the 1x1-conv GEMMs (N3DT_F32 exact; BF16/F16 inputs with
  * fp32 accumulate); blur, bilinear and the RGB pyramid are always fp32.
  * `nb` is the number of feature maps in this call (the binding renders the B merged maps and the
- * background map together, nb = B+1; reference calls the module twice, HeadNeRFNet.py:109,113). */
+ * background map together, nb = B+1; reference calls the module twice, HeadNeRFNet.py:109,113).
+ * Limit: nb * P * P * 32 < 2^31 (the kernels index one map level with 32-bit offsets: 255 maps at 512^2,
+ * 63 at 1024^2); larger batches return N3DT_EINVAL before anything is launched -- split them. */
 size_t n3dt_neural_render_workspace_bytes(const N3dtGeom* g, int nb);
 int n3dt_neural_render_fwd(const N3dtGeom* g, int nb, int precision, const N3dtRenderParams* p, const float* featmap,
                            float* img, void* workspace, size_t workspace_bytes, void* stream);
