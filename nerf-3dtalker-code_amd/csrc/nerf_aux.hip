@@ -386,14 +386,46 @@ __global__ __launch_bounds__(256) void ray_head_mfma_kernel(N3dtGeom g, int bpr,
         dsum_s[t] = ds;
     }
     __syncthreads();
-    for (int i = t; i < RH_RAYS * N3DT_G; i += 256) {
-        const int r = i / N3DT_G, j = i % N3DT_G;
-        const long rg = ray0 + r;
-        float acc = 0.0f;
-        if (rg < nrays_total)
-            for (int k = 0; k < bpr; ++k) acc += pref[r][k] * part[((size_t)rg * bpr + k) * N3DT_PART_STRIDE + j];
-        G[r][j] = acc;
-        if (rayrec && rg < nrays_total) rayrec[(size_t)rg * N3DT_PART_STRIDE + j] = acc;
+    // G[ray][0:192] = sum_k pref[ray][k] * part[ray][k][0:192].  A workgroup's run time is a chain of memory round trips (38 us for
+    // ONE workgroup at one head; diagnostic builds: this phase 13 us of them, the epilogue 10), so the phase issues everything it
+    // needs at once: 16-byte loads (rows are 784 B apart: aligned), six quads per thread, all blocks of a ray, fully unrolled for
+    // the usual one or two blocks per ray.
+    static_assert(N3DT_G % 4 == 0 && (N3DT_PART_STRIDE * 4) % 16 == 0 && RH_RAYS * (N3DT_G / 4) % 256 == 0, "whole quads");
+    constexpr int QPR = N3DT_G / 4, NQ = RH_RAYS * QPR / 256;  // quads per ray row, quads per thread
+    if (bpr <= 2) {
+        f32x4 v[NQ][2];
+        float pf[NQ][2];
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int i = t + 256 * u, r = i / QPR, q = i % QPR;
+            const long rg = min(ray0 + r, nrays_total - 1);
+            const float* p0 = part + (size_t)rg * bpr * N3DT_PART_STRIDE + 4 * q;
+            v[u][0] = *reinterpret_cast<const f32x4*>(p0);
+            v[u][1] = *reinterpret_cast<const f32x4*>(p0 + (bpr == 2 ? N3DT_PART_STRIDE : 0));
+            pf[u][0] = pref[r][0];
+            pf[u][1] = bpr == 2 ? pref[r][1] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int i = t + 256 * u, r = i / QPR, q = i % QPR;
+            f32x4 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = pf[u][0] * v[u][0][e] + pf[u][1] * v[u][1][e];
+            const bool in = ray0 + r < nrays_total;
+            if (!in) a = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            *reinterpret_cast<f32x4*>(&G[r][4 * q]) = a;
+            if (rayrec && in) *reinterpret_cast<f32x4*>(rayrec + (size_t)(ray0 + r) * N3DT_PART_STRIDE + 4 * q) = a;
+        }
+    } else {
+        for (int i = t; i < RH_RAYS * N3DT_G; i += 256) {
+            const int r = i / N3DT_G, j = i % N3DT_G;
+            const long rg = ray0 + r;
+            float acc = 0.0f;
+            if (rg < nrays_total)
+                for (int k = 0; k < bpr; ++k) acc += pref[r][k] * part[((size_t)rg * bpr + k) * N3DT_PART_STRIDE + j];
+            G[r][j] = acc;
+            if (rayrec && rg < nrays_total) rayrec[(size_t)rg * N3DT_PART_STRIDE + j] = acc;
+        }
     }
     __syncthreads();
     if (rayrec && t < RH_RAYS && ray0 + t < nrays_total) {
@@ -439,6 +471,15 @@ __global__ __launch_bounds__(256) void ray_head_mfma_kernel(N3dtGeom g, int bpr,
     for (int i = 0; i < 2; ++i) {
         const int c = 64 * wave + 32 * i + r31;
         const float b2 = tail[N3DT_G * N3DT_C + c];
+        // (the sixteen background values first, from clamped ray indices, then the stores: no load waits behind a store)
+        float bgv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const long rg = min(ray0 + rr, nrays_total - 1);
+            const int ray = (int)(rg % g.n_rays);
+            bgv[r] = merge_feat ? (bg_hwc ? bg_featmap[(size_t)ray * N3DT_C + c] : bg_featmap[(size_t)c * g.n_rays + ray]) : 0.0f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -446,11 +487,7 @@ __global__ __launch_bounds__(256) void ray_head_mfma_kernel(N3dtGeom g, int bpr,
             if (rg >= nrays_total) continue;
             const float fg = acc[i][r] + b2 * wsum_s[rr];
             if (fg_feat) fg_feat[(size_t)rg * N3DT_C + c] = fg;
-            if (merge_feat) {
-                const int ray = (int)(rg % g.n_rays);
-                merge_feat[(size_t)rg * N3DT_C + c] =
-                    fg + (1.0f - wsum_s[rr]) * (bg_hwc ? bg_featmap[(size_t)ray * N3DT_C + c] : bg_featmap[(size_t)c * g.n_rays + ray]);
-            }
+            if (merge_feat) merge_feat[(size_t)rg * N3DT_C + c] = fg + (1.0f - wsum_s[rr]) * bgv[r];
         }
     }
     if (t < RH_RAYS && ray0 + t < nrays_total) {
