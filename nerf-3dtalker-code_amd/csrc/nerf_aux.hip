@@ -443,7 +443,10 @@ __global__ __launch_bounds__(256) void ray_head_mfma_kernel(N3dtGeom g, int bpr,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     const rh_bf16x8* w2frags = reinterpret_cast<const rh_bf16x8*>(tail + n3dt_tail_w2_frags_offset());
-#pragma unroll 2
+#ifndef RH_UNROLL
+#define RH_UNROLL 2
+#endif
+#pragma unroll RH_UNROLL
     for (int ks = 0; ks < N3DT_G / 16; ++ks) {
         const int k0 = 16 * ks + 8 * h;
         rh_bf16x8 a_hi, a_lo;
