@@ -203,7 +203,7 @@ extern "C" void n3dt_launch_pack(const N3dtGeom* g, int precision, const N3dtMlp
 // a few ulp on a bias, inside every mode's budget (the exact-fp32 gate is 1e-3 on RGB, measured 8e-6).
 // grid (B, N3DT_NSTAGE, FOLD_ROWGROUPS), block 256 (4 waves).  The first version ran one THREAD per row (a serial
 // 243-term loop over row-strided, uncoalesced loads): 23 us per call even at B = 1, now a launch latency.
-#define FOLD_ROWGROUPS 12
+#define FOLD_ROWGROUPS 24
 __global__ __launch_bounds__(256) void fold_latents_kernel(N3dtMlpParams p, int S, int A, int U, int merged, const float* __restrict__ shape,
                                                            const float* __restrict__ appea, const float* __restrict__ audio,
                                                            float* __restrict__ fold) {
@@ -234,19 +234,38 @@ __global__ __launch_bounds__(256) void fold_latents_kernel(N3dtMlpParams p, int 
         code[i] = v;
     }
     __syncthreads();
-    for (int o = blockIdx.z * 4 + wave; o < st.N; o += 4 * FOLD_ROWGROUPS) {
-        if (stage == 8) {  // density: one real row
+    if (stage == 8) {  // density: one real row
+        for (int o = blockIdx.z * 4 + wave; o < st.N; o += 4 * FOLD_ROWGROUPS)
             if (lane == 0) out[o] = o == 0 ? p.bias[8][0] : 0.0f;
-            continue;
-        }
-        float acc = 0.0f;
-        if (n_code > 0) {
-            const float* w = p.weight[st.layer] + (size_t)o * ld + col0;
-            for (int i = lane; i < n_code; i += 64) acc = fmaf(w[i], code[i], acc);
+        return;
+    }
+    // FOLD_UNR rows of a wave at a time: the kernel is a chain of load round trips (one per row when the rows went one by one),
+    // so a wave keeps the loads of several rows in flight together
+    constexpr int FOLD_UNR = 4;
+    constexpr int RSTEP = 4 * FOLD_ROWGROUPS;
+    for (int o0 = blockIdx.z * 4 + wave; o0 < st.N; o0 += RSTEP * FOLD_UNR) {
+        float acc[FOLD_UNR];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        for (int u = 0; u < FOLD_UNR; ++u) acc[u] = 0.0f;
+        if (n_code > 0) {
+            const float* w[FOLD_UNR];
+#pragma unroll
+            for (int u = 0; u < FOLD_UNR; ++u) w[u] = p.weight[st.layer] + (size_t)min(o0 + RSTEP * u, st.N - 1) * ld + col0;
+            for (int i = lane; i < n_code; i += 64) {
+                const float cv = code[i];
+#pragma unroll
+                for (int u = 0; u < FOLD_UNR; ++u) acc[u] = fmaf(w[u][i], cv, acc[u]);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                for (int u = 0; u < FOLD_UNR; ++u) acc[u] += __shfl_xor(acc[u], off, 64);
         }
-        if (lane == 0) out[o] = p.bias[st.layer][o] + acc;
+#pragma unroll
+        for (int u = 0; u < FOLD_UNR; ++u) {
+            const int o = o0 + RSTEP * u;
+            if (lane == 0 && o < st.N) out[o] = p.bias[st.layer][o] + acc[u];
+        }
     }
 }
 
@@ -443,10 +462,7 @@ __global__ __launch_bounds__(256) void ray_head_mfma_kernel(N3dtGeom g, int bpr,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     const rh_bf16x8* w2frags = reinterpret_cast<const rh_bf16x8*>(tail + n3dt_tail_w2_frags_offset());
-#ifndef RH_UNROLL
-#define RH_UNROLL 2
-#endif
-#pragma unroll RH_UNROLL
+#pragma unroll 2
     for (int ks = 0; ks < N3DT_G / 16; ++ks) {
         const int k0 = 16 * ks + 8 * h;
         rh_bf16x8 a_hi, a_lo;
