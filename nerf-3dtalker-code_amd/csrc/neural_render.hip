@@ -139,6 +139,47 @@ __global__ void to_rgb_kernel(int nb, int HW, int K, const float* __restrict__ n
     rgb_out[o + 2 * (size_t)HW] = a2;
 }
 
+// The same projection with SIXTEEN lanes per pixel (K a multiple of 64): a lane takes K / 16 channels as 16-byte loads that a
+// pixel's lanes issue side by side (256 contiguous bytes per instruction and pixel; the one-thread-per-pixel form above strides
+// its lanes 4 K bytes apart and walks K / 4 dependent loads: 11 us for two 64 x 64 maps, a launch the whole chip cannot help
+// with since it is 32 workgroups), then a 4-step butterfly.  First level of the 16-bit render path (K = 256).
+__global__ __launch_bounds__(256) void to_rgb16_kernel(int nb, int HW, int K, const float* __restrict__ net, const float* __restrict__ Wt,
+                                                       const float* __restrict__ bias, float* __restrict__ rgb_out) {
+    extern __shared__ float wl[];  // [3][K]
+    for (int i = threadIdx.x; i < 3 * K; i += blockDim.x) wl[i] = Wt[i];
+    __syncthreads();
+    const int l16 = threadIdx.x & 15;
+    size_t pix = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool valid = pix < (size_t)nb * HW;
+    if (!valid) pix = (size_t)nb * HW - 1;  // keep the lane for the shuffles
+    const float* xr = net + pix * K + 4 * l16;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    for (int k = 0; k < K; k += 64) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + k + 4 * l16), w1 = *reinterpret_cast<const f32x4*>(wl + K + k + 4 * l16),
+                    w2 = *reinterpret_cast<const f32x4*>(wl + 2 * K + k + 4 * l16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a0 = fmaf(w0[j], v[j], a0);
+            a1 = fmaf(w1[j], v[j], a1);
+            a2 = fmaf(w2[j], v[j], a2);
+        }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        a0 += __shfl_xor(a0, off, 64);
+        a1 += __shfl_xor(a1, off, 64);
+        a2 += __shfl_xor(a2, off, 64);
+    }
+    if (valid && l16 == 0) {
+        const N3dtDiv dHW = n3dt_div(HW);
+        const size_t img = n3dt_quot(pix, dHW), p = n3dt_rem(pix, dHW), o = img * 3 * (size_t)HW + p;
+        rgb_out[o] = a0 + bias[0];
+        rgb_out[o + HW] = a1 + bias[1];
+        rgb_out[o + 2 * (size_t)HW] = a2 + bias[2];
+    }
+}
+
 __device__ __forceinline__ float bilinear_at(const float* __restrict__ x, int h, int w, int i, int j) {
     // value of the 2x bilinear upsample (align_corners=False) of x[h][w] at output pixel (i, j)
     float si = fmaxf(0.5f * ((float)i + 0.5f) - 0.5f, 0.0f);
