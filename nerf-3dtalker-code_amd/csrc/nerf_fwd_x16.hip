@@ -131,7 +131,9 @@ __device__ __forceinline__ void x16_stage(WS& ws, const float* __restrict__ bias
             }
         });
         if constexpr (LB && ot + 1 < NT) {
-            asm volatile("" : "+v"(bias_nxt));  // landed: it is older than every fragment read awaited in the k-loop above
+            // landed: it is older than every fragment read awaited in the k-loop above (the accumulator rides along: the
+            // statement then cannot move ahead of the loop's last MFMA)
+            asm volatile("" : "+v"(bias_nxt), "+v"(acc[cur][0]));
             bias_cur = bias_nxt;
         }
         X16_T(const unsigned long long s2 = x16_now();)
