@@ -69,12 +69,6 @@ def test_two_rank_gradient_average_equals_full_batch():
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    import time
-    deadline = time.time() + 600
-    while q.empty():  # (SimpleQueue.get() has no timeout: do not hang on a rank that died before answering)
-        assert all(p.exitcode in (None, 0) for p in procs), "a rank failed"
-        assert time.time() < deadline, "ranks did not answer"
-        time.sleep(0.2)
     got = q.get()
     for p in procs:
         p.join(timeout=600)  # a cold `import torch` in a freshly spawned interpreter can take minutes on a busy machine
