@@ -345,6 +345,16 @@ struct WeightStream {
     }
 };
 
+// LeakyReLU(0.2) = max(a, 0.2 a) in two instructions.  As fmaxf() hipcc emits three: IEEE maxnum wants canonical inputs, and an
+// accumulator read is not known to be one, so a v_max_f32 a, a, a goes in front (768 v_max for 384 activations in the C = 256
+// renderer block).  A NaN propagates through v_max_f32 as through the three-instruction form, quieted.
+__device__ __forceinline__ float x16_lrelu02(const float a) {
+    const float b = 0.2f * a;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // one float from LDS, issued from inline asm and NOT awaited: LDS returns in order, so the value has landed once a fragment read
 // issued after it has been awaited (the caller then pins it with asm volatile("" : "+v"(dst)) before the first use)
 template <int OFF>
