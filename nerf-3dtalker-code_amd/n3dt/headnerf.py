@@ -399,6 +399,7 @@ class HeadNeRFNet(nn.Module):
         self.graph_static_outputs = graph_static_outputs
         self._graphs = {}
         self._bg_cache = None
+        self._maps_cache = {}
         # a (strict or not) load_state_dict replaces every weight: drop the packed copies
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_packed())
 
@@ -423,6 +424,7 @@ class HeadNeRFNet(nn.Module):
         write, or use n3dt.checkpoint.load_ckpt, which does."""
         self._pack_cache.clear()
         self._bg_cache = None
+        self._maps_cache.clear()
         self.neural_render.invalidate_packed()
         for e in self._graphs.values():
             e["bg_ver"] = None
@@ -539,11 +541,26 @@ class HeadNeRFNet(nn.Module):
             return self._forward_graph(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats)
         n_pass = 2 if self.hier_sampling else 1
         nb = n_pass * batch_size
-        maps = torch.empty(nb + 1, fs, fs, C, dtype=torch.float32, device=batch_xy.device)
+        maps = self._maps_with_background(nb, batch_xy.device)
         if self.hier_sampling and for_train and fine_u is None:  # the reference's torch.rand(num_temp, NFsample) (NetWorks/utils.py:227)
             fine_u = torch.rand(batch_size * n_r, self.num_sample_fine + 1, device=batch_xy.device, dtype=torch.float32)
-        imgs = self._infer_launch(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand, fine_u, maps)
+        imgs = self._infer_launch(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats, t_rand, fine_u, maps,
+                                  bufs={"bg_in_maps": True})
         return self._result(imgs, batch_size, nb)
+
+    def _maps_with_background(self, nb, dev):
+        """The renderer's input batch [nb + 1, fs, fs, C] (merged maps, then the background map) as scratch kept per (nb, device,
+        stream): the background slot is filled once per parameter version instead of by a copy kernel in every forward (it is 4 us
+        of a 0.64 ms one-head step).  The merged slots are overwritten by every call; the images returned to the caller are separate."""
+        bg = self._bg_hwc()
+        key = (nb, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        ent = self._maps_cache.get(key)
+        if ent is None or ent[0] != self._bg_cache[0]:
+            fs, C = self.featmap_size, self.featmap_nc
+            maps = ent[1] if ent is not None else torch.empty(nb + 1, fs, fs, C, dtype=torch.float32, device=dev)
+            maps[nb].view(fs * fs, C).copy_(bg)
+            self._maps_cache[key] = ent = (self._bg_cache[0], maps)
+        return ent[1]
 
     def _result(self, imgs, batch_size, nb):
         res = {"coarse_dict": {"merge_img": imgs[:batch_size], "bg_img": imgs[nb:]}}
@@ -569,7 +586,7 @@ class HeadNeRFNet(nn.Module):
             self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
                                  z_planes=planes, want_merge=True, want_fg=False,
                                  merge_out=maps[batch_size:nb].view(batch_size, fs * fs, C), workspace=bufs.get("fine_ws"))
-        if "nr_ws" not in bufs:  # (a recorded graph keeps the background map in its static batch: see _forward_graph)
+        if "nr_ws" not in bufs and not bufs.get("bg_in_maps"):  # (a recorded graph keeps the background map in its static batch: see _forward_graph)
             maps[nb].view(fs * fs, C).copy_(self._bg_hwc())
         return self.neural_render.render_hwc(maps, self.precision, img=imgs, ws=bufs.get("nr_ws"))
 
