@@ -495,3 +495,32 @@ def test_oversized_renderer_batches_go_through_in_slices():
         finally:
             nr._max_maps_per_call = None
         assert torch.equal(whole, sliced), prec
+
+
+def test_cached_renderer_batch_follows_the_background_parameter():
+    """forward() keeps its renderer input batch (merged maps + background map) per batch size and stream, with the background slot
+    filled once per parameter version: an in-place update of `neural_render.bg_featmap` (what an optimizer does) must show in the
+    next forward, and a write through `.data` after invalidate_packed()."""
+    from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
+    opt = BaseOptions({"featmap_size": 8, "featmap_nc": 256, "pred_img_size": 32, "num_sample_coarse": 8})
+    net = HeadNeRFNet(opt, False, False, precision="bf16").to(dev())
+    net.load_state_dict(syn.make_state_dict(opt, seed=0, bg_noise=0.1))
+    d = {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in syn.frame_inputs(opt, 2).items()}
+
+    def run(n):
+        with torch.no_grad():
+            o = n("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+                  d["batch_Tvecs"], d["batch_inv_inmats"])["coarse_dict"]
+        return o["merge_img"].clone(), o["bg_img"].clone()
+
+    m0, b0 = run(net)
+    m0b, b0b = run(net)
+    assert torch.equal(m0, m0b) and torch.equal(b0, b0b)
+    with torch.no_grad():
+        net.neural_render.bg_featmap.mul_(0.5)  # version counter moves
+    m1, b1 = run(net)
+    assert float((b1 - b0).abs().max()) > 1e-3
+    net.neural_render.bg_featmap.data.mul_(2.0)  # back to the original values; `.data` writes move no counter
+    net.invalidate_packed()
+    m2, b2 = run(net)
+    assert torch.equal(b2, b0) and torch.equal(m2, m0)
