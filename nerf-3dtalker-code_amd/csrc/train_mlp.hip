@@ -175,30 +175,51 @@ __global__ void train_composite_fwd_kernel(N3dtGeom g, const float* __restrict__
 //   fg = W2 Gray + b2 wsum ; bg_alpha = 1 - wsum ; merge = fg + bg_alpha * bg
 // d_fg_total = d_merge + d_fg ; d_ba_total = d_bg_alpha + sum_c d_merge[c] bg[c]
 // outputs dGray[192] = W2^T d_fg_total ; d_wsum = b2 . d_fg_total - d_ba_total ; dfg_total saved for dW2
+// HB_RAYS rays per workgroup: one workgroup per ray read all of W2 (196 KB) from L2 for 192 x 256 FMAs -- 1.6 GB of L2 reads per
+// call at two heads (71 us); eight rays share each W2 element (20 us)
+#define HB_RAYS 8
 __global__ __launch_bounds__(256) void train_head_bwd_kernel(N3dtGeom g, const float* __restrict__ W2 /*[256][192]*/,
                                                              const float* __restrict__ b2, const float* __restrict__ bg,
                                                              const float* __restrict__ d_merge, const float* __restrict__ d_fg,
                                                              const float* __restrict__ d_ba, float* __restrict__ dfg_total,
-                                                             float* __restrict__ dgray, float* __restrict__ dwsum) {
-    __shared__ float sd[256];
-    __shared__ float red[256];
-    const long rg = blockIdx.x;
-    const int c = threadIdx.x, ray = (int)(rg % g.n_rays);
-    float dm = d_merge ? d_merge[rg * 256 + c] : 0.0f;
-    float df = dm + (d_fg ? d_fg[rg * 256 + c] : 0.0f);
-    sd[c] = df;
-    dfg_total[rg * 256 + c] = df;
-    red[c] = b2[c] * df - (d_merge ? dm * bg[(size_t)c * g.n_rays + ray] : 0.0f);
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (c < off) red[c] += red[c + off];
-        __syncthreads();
+                                                             float* __restrict__ dgray, float* __restrict__ dwsum, long n_rays_total) {
+    __shared__ float sd[HB_RAYS][256];
+    __shared__ float red[HB_RAYS][4];
+    const long rg0 = (long)blockIdx.x * HB_RAYS;
+    const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    const float b2c = b2[c];
+#pragma unroll
+    for (int r = 0; r < HB_RAYS; ++r) {
+        const long rg = rg0 + r;
+        float df = 0.0f, part = 0.0f;
+        if (rg < n_rays_total) {
+            const int ray = (int)(rg % g.n_rays);
+            const float dm = d_merge ? d_merge[rg * 256 + c] : 0.0f;
+            df = dm + (d_fg ? d_fg[rg * 256 + c] : 0.0f);
+            dfg_total[rg * 256 + c] = df;
+            part = b2c * df - (d_merge ? dm * bg[(size_t)c * g.n_rays + ray] : 0.0f);
+        }
+        sd[r][c] = df;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (lane == 0) red[r][wave] = part;
     }
-    if (c == 0) dwsum[rg] = red[0] - (d_ba ? d_ba[rg] : 0.0f);
+    __syncthreads();
+    if (c < HB_RAYS && rg0 + c < n_rays_total)
+        dwsum[rg0 + c] = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]) - (d_ba ? d_ba[rg0 + c] : 0.0f);
     if (c < 192) {
-        float acc = 0.0f;
-        for (int k = 0; k < 256; ++k) acc = fmaf(W2[k * 192 + c], sd[k], acc);
-        dgray[rg * 192 + c] = acc;
+        float acc[HB_RAYS];
+#pragma unroll
+        for (int r = 0; r < HB_RAYS; ++r) acc[r] = 0.0f;
+#pragma unroll 4
+        for (int k = 0; k < 256; ++k) {
+            const float w = W2[k * 192 + c];
+#pragma unroll
+            for (int r = 0; r < HB_RAYS; ++r) acc[r] = fmaf(w, sd[r][k], acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < HB_RAYS; ++r)
+            if (rg0 + r < n_rays_total) dgray[(rg0 + r) * 192 + c] = acc[r];
     }
 }
 
@@ -630,8 +651,8 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
     (void)hipMemsetAsync(ws + wl.bc, 0, sizeof(float) * 385, s);  // re-used as the [d br0 | d bd] accumulator (Wc's bias is not needed in backward)
     if (d_shape) (void)hipMemsetAsync(d_shape, 0, sizeof(float) * (size_t)B * S, s);
     // ---- head: RGB_layer_2 once per ray + merge (models.py:82, HeadNeRFNet.py:103-112)
-    hipLaunchKernelGGL(train_head_bwd_kernel, dim3((unsigned)Rr), dim3(256), 0, s, *g, p->weight[11], p->bias[11], bg_featmap, d_merge,
-                       d_fg, d_ba, dfg_total, ws + wl.dgray, ws + wl.dwsum);
+    hipLaunchKernelGGL(train_head_bwd_kernel, dim3((unsigned)((Rr + HB_RAYS - 1) / HB_RAYS)), dim3(256), 0, s, *g, p->weight[11], p->bias[11], bg_featmap, d_merge,
+                       d_fg, d_ba, dfg_total, ws + wl.dgray, ws + wl.dwsum, (long)Rr);
     hipLaunchKernelGGL(train_bg_b2_grad_kernel, dim3((g->n_rays + BG_RAYS - 1) / BG_RAYS), dim3(256), 0, s, *g, saved + sv.ray, d_merge, dfg_total, d_bg_featmap,
                        gp->bias[11]);
     {   // dW2[256][192] += dfg_total^T Gray
