@@ -487,7 +487,10 @@ static void launch_colsum(const float* X, long ldx, int rows_per_frame, int fram
 //   d_shape[f] = W0[:,63:63+S]^T db0' + W5[:,63:63+S]^T db5' ; d_audio[f] = W0[:,63+S:]^T db0' ; d_appea[f] = Wr1[:,384:]^T dbr1'
 //   dW0[:,63:] += sum_f db0'[f] (x) [shape_f, audio_f] ; dW5[:,63:63+S] += sum_f db5'[f] (x) shape_f ; dWr1[:,384:] += ...
 //   db0 += sum_f db0'[f] (same for b5, br1)
-// grid (3, B), block 256
+// grid (3, B, FOLDB_ROWGROUPS), block 256: a workgroup takes a slice of the layer's output rows (as one workgroup per (table,
+// frame) the kernel was six workgroups walking 384 rows each, one atomic per row and thread: 60 us of latency at two heads);
+// d_shape / d_appea / d_audio are accumulated with atomics over the row groups: the launcher zeroes them first
+#define FOLDB_ROWGROUPS 16
 __global__ void train_fold_bwd_kernel(N3dtMlpParams p, N3dtMlpGrads gp, int S, int A, int U, int B, const float* __restrict__ shape,
                                       const float* __restrict__ appea, const float* __restrict__ audio,
                                       const float* __restrict__ dfold, float* __restrict__ d_shape, float* __restrict__ d_appea,
@@ -503,23 +506,34 @@ __global__ void train_fold_bwd_kernel(N3dtMlpParams p, N3dtMlpGrads gp, int S, i
     __shared__ float sdb[384];
     for (int i = t; i < nout; i += blockDim.x) sdb[i] = db[i];
     __syncthreads();
+    const int per = (nout + FOLDB_ROWGROUPS - 1) / FOLDB_ROWGROUPS;
+    const int o0 = blockIdx.z * per, o1 = min(nout, o0 + per);
     // bias gradient (each frame adds its share)
-    for (int o = t; o < nout; o += blockDim.x) atomicAdd(&gp.bias[layer][o], sdb[o]);
+    for (int o = o0 + t; o < o1; o += blockDim.x) atomicAdd(&gp.bias[layer][o], sdb[o]);
     // code gradients and latent weight columns
     for (int i = t; i < ncode; i += blockDim.x) {
         float code;
         if (which == 2) code = appea[(size_t)f * A + i];
         else code = i < S ? shape[(size_t)f * S + i] : audio[(size_t)f * U + (i - S)];
         float acc = 0.0f;
-        for (int o = 0; o < nout; ++o) {
+#pragma unroll 4
+        for (int o = o0; o < o1; ++o) {
             acc = fmaf(p.weight[layer][(size_t)o * ld + col0 + i], sdb[o], acc);
             atomicAdd(&gp.weight[layer][(size_t)o * ld + col0 + i], sdb[o] * code);
         }
-        if (which == 2) { if (d_appea) d_appea[(size_t)f * A + i] = acc; }
+        if (which == 2) { if (d_appea) atomicAdd(&d_appea[(size_t)f * A + i], acc); }
         else if (i < S) { if (d_shape) atomicAdd(&d_shape[(size_t)f * S + i], acc); }
-        else if (d_audio) d_audio[(size_t)f * U + (i - S)] = acc;
+        else if (d_audio) atomicAdd(&d_audio[(size_t)f * U + (i - S)], acc);
     }
     (void)B;
+}
+static void launch_fold_bwd(const N3dtMlpParams* p, const N3dtMlpGrads* gp, int S, int A, int U, int B, const float* shape, const float* appea,
+                            const float* audio, const float* dfold, float* d_shape, float* d_appea, float* d_audio, hipStream_t s) {
+    // (d_shape is zeroed by the callers at the top of their backward: two tables add into it)
+    if (d_appea) (void)hipMemsetAsync(d_appea, 0, sizeof(float) * (size_t)B * A, s);
+    if (d_audio && U > 0) (void)hipMemsetAsync(d_audio, 0, sizeof(float) * (size_t)B * U, s);
+    hipLaunchKernelGGL(train_fold_bwd_kernel, dim3(3, B, FOLDB_ROWGROUPS), dim3(256), 0, s, *p, *gp, S, A, U, B, shape, appea, audio, dfold, d_shape,
+                       d_appea, d_audio);
 }
 
 // scatter the packed gradients back: dW5[:,0:63] += dW5'[:,0:63]; dW5[:,63+S:] += dW5'[:,64:]; dWr0 += dWc[0:384]; dwd += dWc[384]
@@ -730,8 +744,7 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
     }
     hipLaunchKernelGGL(train_unpack_grads_kernel, dim3((384 * 448 + 255) / 256), dim3(256), 0, s, *gp, S, ws + wl.dw5p, ws + wl.dwc,
                        ws + wl.bc);
-    hipLaunchKernelGGL(train_fold_bwd_kernel, dim3(3, B), dim3(256), 0, s, *p, *gp, S, A, U, B, shape, appea, audio, dfold, d_shape,
-                       d_appea, d_audio);
+    launch_fold_bwd(p, gp, S, A, U, B, shape, appea, audio, dfold, d_shape, d_appea, d_audio, s);
 }
 
 #include "train_x16.inc"
