@@ -18,9 +18,14 @@ Extra objects in the line:
                 inside the timed region) against the dense bf16 MFMA peak.
   cpu_baseline  the CPU restatement (oracle/, an OpenMP port -- the reference's Python cannot
                 travel to the GPU box) timed on this host's cores on one frame of the workload.
+  parity_check  (N = 1) the frame the CPU baseline rendered, rendered by the GPU in bf16 / bf16x3 / fp32 outside the timed
+                region: RGB L-inf against the oracle on the bench's weights and on the sharp-density `contrast` weights.
+                The run exits non-zero when fp32 or bf16x3 exceed 1e-3.
+  parity_grade  (N = 1) throughput of the MFMA mode that holds 1e-3 on every fixture (bf16x3), beside the bf16 headline.
+  sustained     (N = 1) >= 3 s of back-to-back headline steps: ms/step and the fused kernel's mean launch time there.
   extra         (N = 1 only) the other BASELINE configurations and modes, a few timed steps each:
                 cfg2-N (512^2 rays), cfg2-R in exact fp32, cfg2-R one head (latency), cfg3 training
-                step in bf16 and fp32, cfg4, cfg5.
+                step in bf16 and fp32, cfg4 (R and N), cfg5 (R and N), single-image fitting in both training precisions.
 """
 import argparse
 import ctypes
@@ -72,10 +77,13 @@ class Ctx:
         if self.world != args.gpus:
             raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with `python bench.py --gpus N` or "
                              "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)" % (args.gpus, self.world))
+        self.cpus_bound = None
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # one rank per GPU: keep the rank's host threads on the GPU's NUMA node (before anything touches the device)
+            self.cpus_bound = _load_launcher().bind_rank_to_gpu_numa(local_rank)
         assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
         # one process per GPU.  N3DT_DIST_BACKEND=gloo is a rehearsal knob for boxes with fewer GPUs than ranks
         # (ranks then share devices round-robin); the real runs use nccl = RCCL over xGMI.
@@ -134,14 +142,14 @@ def build(ctx, config, precision, batch, rays="R", train_precision=None, first_f
     net = HeadNeRFNet(opt, include_vd=False, hier_sampling=False, precision=precision,
                       train_precision=train_precision or "fp32").to(ctx.dev)
     net.load_state_dict(sd, strict=True)
-    n_side = 512 if rays == "N" else None
+    n_side = pred if rays == "N" else None   # reading N: one ray per output pixel (512^2 / 256^2 / 1024^2)
     # every rank renders its own frames: frame indices rank*B .. rank*B+B-1
     inp = syn.frame_inputs(opt, batch, n_side=n_side, first_frame=ctx.rank * batch if first_frame is None else first_frame)
     d = {k: (v.to(ctx.dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
     return opt, sd, net, d
 
 
-def run_render(ctx, config, precision, batch, rays, steps, warmup, prof=True):
+def run_render(ctx, config, precision, batch, rays, steps, warmup, prof=True, keep_kernel_ms=False):
     """forward("test") of `batch` heads per rank per step (reading N: the feature stage on 512^2 rays).
     prof=True: the fused kernel's launches are timed by hipEvents INSIDE the timed region (the headline's roofline figure);
     forward() then runs kernel by kernel.  prof=False: the timed region is forward() as callers get it (hipGraph replay),
@@ -190,13 +198,14 @@ def run_render(ctx, config, precision, batch, rays, steps, warmup, prof=True):
     points = batch * n_rays * ns
     achieved = points * FLOP_PER_POINT / (kern_ms * 1e-3) / 1e12
     return {
+        "kernel_ms_all": [ms[i] for i in range(n_rec.value)] if keep_kernel_ms else None,
         "opt": opt, "sd": sd, "elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps,
         "frames_per_s": ctx.world * batch * steps / elapsed, "kern_ms": kern_ms, "points": points, "n_rays": n_rays,
         "achieved": achieved, "frac": achieved / PEAK_TFLOPS[precision],
         "executed_tflops": points * flop_per_point_executed(precision) / (kern_ms * 1e-3) / 1e12, "graph_replay": bool(rays == "R" and not prof and net.use_graph),
         "workload": ("%s-R: %d heads/GPU/step, %dx%d rays x %d samples -> fused MLP+composite -> neural renderer "
                      "-> %dx%d RGB (+ background image)" % (config, batch, fs, fs, ns, pred, pred)) if rays == "R" else
-                    ("%s-N: %d heads/GPU/step, 512x512 rays x %d samples, feature stage only" % (config, batch, ns)),
+                    ("%s-N: %d heads/GPU/step, %dx%d rays x %d samples, feature stage only" % (config, batch, pred, pred, ns)),
     }
 
 
@@ -217,9 +226,12 @@ def run_train(ctx, config, train_precision, batch, steps, warmup, audio2style_bu
         optim_a2s = torch.optim.Adam(bucket.parameters(), lr=1e-7, betas=(0.5, 0.999))
     gt = torch.full((batch, 3, pred, pred), 0.5, device=ctx.dev)
     mask = disk_mask(batch, pred).to(ctx.dev)
+    reducer = None
     if ctx.world > 1:
         parallel.broadcast_parameters(net)
-    reduce_params = list(net.parameters()) + (list(bucket.parameters()) if bucket is not None else [])
+        # two buckets, reduced in place (no cat, no copy-back): HeadNeRFNet's gradient arena goes out from inside backward as soon
+        # as its last gradient is in, the co-trained module's bucket after it; both are joined before the optimizer steps
+        reducer = parallel.GradReducer([net.grad_arena()] + ([bucket.parameters()] if bucket is not None else []), ctx.world)
 
     def step():
         pred_ = net("train", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"],
@@ -230,7 +242,8 @@ def run_train(ctx, config, train_precision, batch, steps, warmup, audio2style_bu
         loss.backward()
         if bucket is not None:
             bucket.fill_grad(1e-3)  # the LSTM's backward is outside the path; its gradient bytes are not
-        parallel.allreduce_gradients(reduce_params, ctx.world)
+        if reducer is not None:
+            reducer.wait()
         optim.step()
         if optim_a2s is not None:
             optim_a2s.step()
@@ -245,7 +258,9 @@ def run_train(ctx, config, train_precision, batch, steps, warmup, audio2style_bu
     elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
     return {
         "elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "frames_per_s": ctx.world * batch * steps / elapsed,
-        "allreduce_bytes_per_step": 4 * sum(p.numel() for p in reduce_params) if ctx.world > 1 else 0,
+        "allreduce_bytes_per_step": reducer.bytes_per_step() if reducer is not None else 0,
+        "allreduce_buckets": [a.numel * 4 for a in reducer.arenas] if reducer is not None else [],
+        "allreduce_launched_inside_backward": reducer.hook_launches if reducer is not None else 0,
         "workload": "%s: %d heads/GPU/step, %dx%d rays x %d samples -> %dx%d, 3 MSE terms, Adam" % (
             "cfg3" if config == "cfg2" else config + "-train", batch, fs, fs, ns, pred, pred),
     }
@@ -296,32 +311,107 @@ def cpu_info():
     return model, os.cpu_count() or 1, avail
 
 
+def cgroup_cpu_quota():
+    """CPUs this process may use according to its cgroup (v2 cpu.max, v1 cfs quota), or None when unlimited / unreadable."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = float(f.read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(opt, sd, rays):
-    """The C restatement (oracle/) on this host: one cfg2-R frame, at the box's CPU share and at 8 threads."""
+    """The C restatement (oracle/) on this host: one cfg2-R frame at 8 threads, at 16 (the box's per-GPU CPU share) and at
+    min(nproc, 64) (OMP_NUM_THREADS = nproc and 8); `value` is the best of them, `cores` the threads it used.
+    Returns (record, oracle output of that frame) -- the output is what parity_check() compares the GPU's frame with."""
     from n3dt import synthetic as syn
     from oracle import oracle as orc
     model, nproc, avail = cpu_info()
-    # the GPU box exposes every host core but grants a 16-CPU share per GPU: more threads only thrash
-    cores = max(1, min(avail, int(os.environ.get("N3DT_CPU_THREADS", "16"))))
     one = syn.frame_inputs(opt, 1)
     skip = rays == "N"
+    ref = {}
 
     def timed(threads, reps):
         orc.set_num_threads(threads)
         orc.forward(sd, opt, one, skip_neural_render=skip)  # warm (page-in, thread pool)
         t1 = time.perf_counter()
         for _ in range(reps):
-            orc.forward(sd, opt, one, skip_neural_render=skip)
+            ref["out"] = orc.forward(sd, opt, one, skip_neural_render=skip)
         return (time.perf_counter() - t1) / reps
 
-    s_main = timed(cores, 2)
-    s_8 = timed(min(8, avail), 1) if cores != 8 else s_main
-    return {
-        "value": 1.0 / s_main, "unit": "frames/s", "cores": cores, "kind": "port",
-        "sample": "2 x 1 frame of the cfg2-R workload (64x64 rays x 64 samples -> 512^2), fp32 OpenMP C restatement (oracle/)",
-        "cpu_model": model, "nproc": nproc, "cpus_available": avail,
-        "value_8_threads": 1.0 / s_8, "seconds_per_frame": s_main, "seconds_per_frame_8_threads": s_8,
+    counts = sorted({max(1, min(avail, c)) for c in (8, int(os.environ.get("N3DT_CPU_THREADS", "16")), min(nproc, 64))})
+    secs = {c: timed(c, 2 if c == 16 else 1) for c in counts}
+    best = min(secs, key=secs.get)
+    orc.set_num_threads(best)
+    rec = {
+        "value": 1.0 / secs[best], "unit": "frames/s", "cores": best, "kind": "port",
+        "sample": "one frame of the cfg2-R workload (64x64 rays x 64 samples -> 512^2) per thread count (two at 16), "
+                  "fp32 OpenMP C restatement (oracle/); value = the best thread count",
+        "cpu_model": model, "nproc": nproc, "cpus_available": avail, "cgroup_cpu_quota": cgroup_cpu_quota(),
+        "seconds_per_frame": secs[best], "seconds_per_frame_by_threads": {str(c): secs[c] for c in counts},
+        "value_8_threads": 1.0 / secs[min(counts, key=lambda c: abs(c - 8))],
     }
+    return rec, ref["out"]
+
+
+PARITY_GATE = 1e-3   # north_star: RGB L-inf vs the reference CPU path; held by fp32 and bf16x3 on every fixture
+
+
+def parity_check(ctx, opt, sd, ref_seed0):
+    """The driver line proves its own output: ONE cfg2-R frame (frame 0 of the synthetic stream, the frame the CPU baseline
+    ran) rendered by the GPU in bf16 / bf16x3 / fp32, outside the timed region, against the oracle's image of it -- on the
+    bench's seed-0 weights and on the sharp-density `contrast` weights (syn.contrast_state_dict: alpha saturates on a third of
+    the rays; what a trained head looks like to the arithmetic).  Values are RGB L-inf over merge_img and bg_img."""
+    import numpy as np
+    import torch
+    from n3dt import HeadNeRFNet, synthetic as syn
+    from oracle import oracle as orc
+    one = syn.frame_inputs(opt, 1)
+    d = {k: (v.to(ctx.dev) if torch.is_tensor(v) else v) for k, v in one.items()}
+    out = {}
+    for name, weights, ref in (("seed0", sd, ref_seed0), ("contrast", syn.contrast_state_dict(opt, seed=0), None)):
+        if ref is None or "merge_img" not in ref:
+            ref = orc.forward(weights, opt, one)
+        errs = {}
+        for prec in ("bf16", "bf16x3", "fp32"):
+            net = HeadNeRFNet(opt, include_vd=False, hier_sampling=False, precision=prec).to(ctx.dev)
+            net.load_state_dict(weights, strict=True)
+            with torch.no_grad():
+                r = net("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"],
+                        d["batch_Rmats"], d["batch_Tvecs"], d["batch_inv_inmats"])["coarse_dict"]
+            torch.cuda.synchronize()
+            errs[prec] = max(float(np.abs(r["merge_img"].cpu().numpy() - ref["merge_img"]).max()),
+                             float(np.abs(r["bg_img"].cpu().numpy() - ref["bg_img"]).max()))
+            del net
+        out[name] = errs
+    torch.cuda.empty_cache()
+    ok = all(out[w][p] <= PARITY_GATE for w in out for p in ("bf16x3", "fp32"))
+    return {"bf16": out["seed0"]["bf16"], "bf16x3": out["seed0"]["bf16x3"], "fp32": out["seed0"]["fp32"],
+            "contrast": out["contrast"], "gate": PARITY_GATE, "gated_modes": ["bf16x3", "fp32"], "ok": ok,
+            "what": "RGB L-inf (merge_img and bg_img) of one cfg2-R frame, GPU vs the CPU oracle, seed-0 weights; "
+                    "`contrast` = the same on the sharp-density weights"}
+
+
+def sustained(ctx, args, ms_per_step):
+    """>= 3 s of back-to-back headline steps: the fused kernel is power-limited, so a 0.16 s window flatters it."""
+    import numpy as np
+    steps = int(max(50, min(2000, 3300.0 / max(ms_per_step, 0.1))))
+    r = run_render(ctx, args.config, args.precision, args.batch, args.rays, steps, 2, prof=True, keep_kernel_ms=True)
+    k = np.asarray(r["kernel_ms_all"], dtype=np.float64)
+    n10 = max(1, len(k) // 10)
+    return {"steps": steps, "seconds": r["elapsed"], "ms_per_step": r["ms_per_step"], "frames_per_s": r["frames_per_s"],
+            "fused_mlp_kernel_ms_mean": float(k.mean()), "fused_mlp_kernel_ms_first_tenth": float(k[:n10].mean()),
+            "fused_mlp_kernel_ms_last_tenth": float(k[-n10:].mean()), "roofline_frac": r["frac"],
+            "what": "the headline step repeated back to back for >= 3 s; kernel times by hipEvents around every launch"}
 
 
 def extras(ctx):
@@ -356,7 +446,12 @@ def extras(ctx):
     rec("cfg4_train_bf16_b2", "fused bf16 training path", lambda k, w: run_train(ctx, "cfg4", "bf16", 2, k, w), 5, 2)
     rec("cfg4_fit_bf16_b1", "single-image fitting iteration (256^2 geometry, as model_Reso32), fused bf16 training path",
         lambda k, w: run_fit(ctx, "cfg4", "bf16", k, w), 10, 3)
+    rec("cfg4_fit_fp32_b1", "single-image fitting iteration, exact fp32 training path (the mode for entry-wise camera gradients)",
+        lambda k, w: run_fit(ctx, "cfg4", "fp32", k, w), 5, 2)
     rec("cfg5_bf16_b4", "bf16", lambda k, w: run_render(ctx, "cfg5", "bf16", 4, "R", k, w, prof=False), 10, 3)
+    rec("cfg4-N_bf16_b4", "bf16, reading N: 256^2 rays per head", lambda k, w: run_render(ctx, "cfg4", "bf16", 4, "N", k, w, prof=False), 4, 2)
+    rec("cfg5-N_bf16_b1", "bf16, reading N: 1024^2 rays x 96 samples = 272 TFLOP per frame",
+        lambda k, w: run_render(ctx, "cfg5", "bf16", 1, "N", k, w, prof=False), 2, 1)
     return out
 
 
@@ -407,9 +502,12 @@ def main():
                 "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": tp, "data": "synthetic",
                 "config": {"workload": r["workload"],
-                           "parallelism": "frames sharded over %d rank(s), one flat gradient all-reduce per step "
-                                          "(HeadNeRFNet + a 21.5 M-parameter Audio2style stand-in bucket)" % ctx.world,
-                           "allreduce_bytes_per_step": r["allreduce_bytes_per_step"], "ranks_seen_by_backend": seen},
+                           "parallelism": "frames sharded over %d rank(s); gradients averaged in place in two flat buckets per step "
+                                          "(HeadNeRFNet's arena, launched from inside backward; then a 21.5 M-parameter Audio2style "
+                                          "stand-in)" % ctx.world,
+                           "allreduce_bytes_per_step": r["allreduce_bytes_per_step"], "allreduce_buckets": r["allreduce_buckets"],
+                           "allreduce_launched_inside_backward": r["allreduce_launched_inside_backward"],
+                           "cpus_bound_per_rank": ctx.cpus_bound, "ranks_seen_by_backend": seen},
             }), flush=True)
         ctx.close()
         return
@@ -442,7 +540,7 @@ def main():
                 "workload": r["workload"],
                 "frames_per_gpu_per_step": args.batch, "rays_per_frame": r["n_rays"], "samples_per_ray": ns,
                 "parallelism": "frames sharded over %d rank(s), no data-path collective" % ctx.world,
-                "ranks_seen_by_backend": seen,
+                "ranks_seen_by_backend": seen, "cpus_bound_per_rank": ctx.cpus_bound,
             },
             "roofline": {
                 "kernel": {"fp32": "nerf_fwd_f32_kernel", "bf16x3": "nerf_fwd_x16s_kernel"}.get(args.precision, "nerf_fwd_x16_kernel"),
@@ -453,14 +551,31 @@ def main():
                 "executed_tflops": r["executed_tflops"],
             },
         }
+    parity_ok = True
     if ctx.world == 1:
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(r["opt"], r["sd"], args.rays)
+            res["cpu_baseline"], ref = cpu_baseline(r["opt"], r["sd"], args.rays)
+            if args.rays == "R" and args.config == "cfg2":
+                # the line proves its own output: the frame the CPU just rendered, on the GPU, three precisions, two weight sets
+                res["parity_check"] = parity_check(ctx, r["opt"], r["sd"], ref)
+                parity_ok = res["parity_check"]["ok"]
         if default_workload and not args.no_extras:
+            res["sustained"] = sustained(ctx, args, r["ms_per_step"])
             res["extra"] = extras(ctx)
+            x3 = res["extra"].get("cfg2-R_bf16x3_b16", {})
+            if "frames_per_s" in x3:
+                # the bf16 headline holds 1e-3 only on init-scale weights (parity_check.contrast); the MFMA mode that holds it
+                # everywhere is bf16x3 -- its throughput is the parity-grade figure
+                res["parity_grade"] = {"mode": "bf16x3", "frames_per_s": x3["frames_per_s"], "ms_per_step": x3["ms_per_step"],
+                                       "roofline_frac": x3["roofline_frac"], "fused_mlp_kernel_ms": x3["fused_mlp_kernel_ms"],
+                                       "rgb_linf_seed0": res.get("parity_check", {}).get("bf16x3"),
+                                       "rgb_linf_contrast": res.get("parity_check", {}).get("contrast", {}).get("bf16x3")}
     if ctx.rank == 0:
         print(json.dumps(res), flush=True)
     ctx.close()
+    if not parity_ok:
+        sys.stderr.write("bench.py: parity_check FAILED (fp32 / bf16x3 RGB L-inf above %g): %s\n" % (PARITY_GATE, json.dumps(res["parity_check"])))
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -108,6 +108,7 @@ class NeuralRenderer(nn.Module):
         self._packed_sig = {}  # workspace address -> (parameter versions, nb, precision) its packed block weights were made from
         self._own_ws = {}
         self.train_precision = "fp32"  # "bf16": matrix products of the differentiable path on bf16 MFMA
+        self._arena_owner = None        # the HeadNeRFNet whose gradient arena this renderer's backward writes into
         self.featmap_size = featmap_size
         self.n_feat = feat_nc
         self.out_dim = out_dim
@@ -179,7 +180,7 @@ class NeuralRenderer(nn.Module):
 
     def render_hwc(self, featmap_hwc, precision="fp32", img=None, ws=None):
         """[nb, fs, fs, C] ray-major feature maps -> [nb, 3, P, P].  img / ws: caller-owned buffers (nothing is allocated
-        then); without `ws` the module keeps one workspace per (nb, device, stream), which also holds its packed weights."""
+        then); without `ws` the module keeps one grow-only workspace per (device, stream), which also holds its packed weights."""
         nb = featmap_hwc.shape[0]
         assert featmap_hwc.is_contiguous()
         # the kernels index one map level with 32-bit offsets (nb x output pixels x 32 channels < 2^31: 255 maps at 512^2,
@@ -194,11 +195,18 @@ class NeuralRenderer(nn.Module):
             return out
         geom = self._geom(nb)
         if ws is None:
+            # ONE grow-only workspace per (device, stream), sized for the largest batch seen (a caller whose batch varies -- a
+            # last partial batch, validation at 1 next to sweeps at 16 -- must not keep a workspace per size alive).  The
+            # packed block weights sit at an offset that depends on nb; the pack signature carries nb, so a different nb re-packs.
             dev = featmap_hwc.device
-            key = (nb, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+            key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+            need = ops.neural_render_workspace_bytes(geom, nb)
             ws = self._own_ws.get(key)
-            if ws is None:
-                ws = self._own_ws[key] = torch.empty(ops.neural_render_workspace_bytes(geom, nb), dtype=torch.uint8, device=dev)
+            if ws is None or ws.numel() < need:
+                if ws is not None:
+                    self._packed_sig.pop(ws.data_ptr(), None)
+                ws = self._own_ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+                self._packed_sig.pop(ws.data_ptr(), None)  # (a fresh allocation may sit where a released one sat)
         rp = self.ensure_packed(nb, precision, ws)
         return ops.neural_render_fwd(geom, nb, rp, featmap_hwc, _lib.PRECISIONS[precision], img=img, ws=ws, reuse_packed=True)
 
@@ -248,17 +256,27 @@ class _RenderFn(torch.autograd.Function):
         ctx.cam = (xy, R, T, Kinv, t_rand) if ctx.want_cam else None
         ctx.bg_shape = bg_featmap.shape
         ctx.mlp_shapes = [t.shape for t in mlp]
+        ctx.net, ctx.param_objs = net, list(mlp) + [bg_featmap]
         return out["merge_feat"]
 
     @staticmethod
     def backward(ctx, d_merge):
         ws, bs, shape_c, appea_c, audio_c, bg = ctx.keep
         geom = ctx.geom
-        gws, gbs = _zeros_like_many(ws), _zeros_like_many(bs)
+        # gradient buffers: slices of the module's persistent arena (zeroed by one fill per backward pass, and what a
+        # multi-GPU step all-reduces in place) -- or fresh zeroed buffers when the arena cannot be used (see FlatGrads.hand_out)
+        views = ctx.net._hand_out_grads(ctx.param_objs)
+        if views is None:
+            gws, gbs, d_bg_out = _zeros_like_many(ws), _zeros_like_many(bs), None
+        else:
+            gws = [v.view(w.shape) for v, w in zip(views[:12], ws)]
+            gbs, d_bg_out = views[12:24], views[24].view(geom.feat_nc, geom.n_rays)
         d_bg, d_shape, d_appea, d_audio, d_R, d_T = ops.render_bwd(geom, ops.mlp_params(ws, bs), ops.mlp_params(gws, gbs), shape_c,
-                                                                   appea_c, audio_c, bg, d_merge.contiguous(), ctx.saved, ctx.cam, ctx.prec)
+                                                                   appea_c, audio_c, bg, d_merge.contiguous(), ctx.saved, ctx.cam, ctx.prec,
+                                                                   d_bg=d_bg_out)
         ctx.saved = None
         grads = [g.view(s) for g, s in zip(gws + gbs, ctx.mlp_shapes)]
+        del gws, gbs, views, d_bg_out  # the returned views must be the only references (autograd then adopts them as .grad)
         if d_T is not None:
             d_T = d_T.view(ctx.T_shape)
         return (None, None, None, None, None, d_R, d_T, d_shape, d_appea, d_audio, d_bg.view(ctx.bg_shape), *grads)
@@ -278,16 +296,21 @@ class _NeuralRenderFn(torch.autograd.Function):
         img, saved = ops.neural_render_train_fwd(geom, nb, rp, fm, ctx.prec)
         ctx.nr, ctx.geom, ctx.nb, ctx.saved, ctx.keep = nr, geom, nb, saved, (tensors, fm)
         ctx.shapes = [t.shape for t in flat]
+        ctx.param_objs = list(flat)
         return img
 
     @staticmethod
     def backward(ctx, d_img):
         tensors, fm = ctx.keep
-        gt = _zeros_like_many(list(tensors))
+        owner = ctx.nr._arena_owner
+        views = owner._hand_out_grads(ctx.param_objs) if owner is not None else None
+        gt = _zeros_like_many(list(tensors)) if views is None else [v.view(t.shape) for v, t in zip(views, tensors)]
         d_feat = ops.neural_render_bwd(ctx.geom, ctx.nb, ctx.nr._rparams_from(tensors), ctx.nr._rparams_from(gt), fm,
                                        d_img.contiguous(), ctx.saved, ctx.prec)
         ctx.saved = None
-        return (None, d_feat, *[g.view(s) for g, s in zip(gt, ctx.shapes)])
+        grads = [g.view(s) for g, s in zip(gt, ctx.shapes)]
+        del gt, views
+        return (None, d_feat, *grads)
 
 
 class FineSample(nn.Module):
@@ -373,7 +396,7 @@ class HeadNeRFNet(nn.Module):
         super().__init__()
         # hier_sampling=True: the reference builds FineSample + a second MLP (HeadNeRFNet.py:67-74) but its call site omits
         # two arguments (:182-185) and raises TypeError; here the fine pass runs, with those arguments supplied
-        # (inference and training; camera gradients through the fine pass are the one thing not built)
+        # (inference and training, camera gradients included: test_gradients_through_the_hierarchical_pass_including_the_cameras)
         if include_vd:
             raise NotImplementedError("include_vd=True is never used by the reference's callers and not built here")
         self.hier_sampling = hier_sampling
@@ -387,7 +410,14 @@ class HeadNeRFNet(nn.Module):
         self._build_info(opt)
         self._build_tool_funcs()
         self.neural_render.train_precision = train_precision
+        object.__setattr__(self.neural_render, "_arena_owner", self)  # (not a sub-module registration: it is the parent)
         self._pack_cache = {}
+        # use_grad_arena: the backward kernels accumulate into slices of ONE persistent flat buffer (grad_arena()) and those
+        # slices become the parameters' .grad -- one fill per step instead of an allocation + fill per tensor list, and the
+        # buffer a data-parallel step all-reduces in place (n3dt/parallel.py).  A `.grad` tensor is therefore overwritten by
+        # the next backward that follows a zero_grad(set_to_none=True): keep a clone, not a reference, to look at it later.
+        self.use_grad_arena = True
+        self._grad_arena = None
         # use_graph=True (or N3DT_GRAPH=1): mode="test" forwards are recorded once per call shape into a hipGraph and replayed
         # with one launch (see _forward_graph).  OFF by default: measured on MI355X / ROCm 7.2 a replay is 3-7 % SLOWER than the
         # stream-ordered launches it replaces (one head: 0.72-0.74 ms against 0.68-0.70; config 4: 5 570 against 5 980 frames/s)
@@ -403,6 +433,23 @@ class HeadNeRFNet(nn.Module):
         # a (strict or not) load_state_dict replaces every weight: drop the packed copies
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_packed())
 
+    def grad_arena(self):
+        """The persistent flat gradient buffer over this module's trainable parameters (n3dt.parallel.FlatGrads), built on
+        first use and rebuilt when the parameter list, a requires_grad flag or the device changed."""
+        from . import parallel
+        params = [p for p in self.parameters() if p.requires_grad]
+        a = self._grad_arena
+        if a is None or not a.matches(params):
+            a = self._grad_arena = parallel.FlatGrads(params)
+            for p in self.parameters():
+                p._n3dt_arena = a if p.requires_grad else None
+        return a
+
+    def _hand_out_grads(self, params):
+        if not self.use_grad_arena or not all(p.requires_grad for p in params):
+            return None
+        return self.grad_arena().hand_out(params)
+
     def _bg_hwc(self):
         """neural_render.bg_featmap [1,C,fs,fs] as the kernels read it, ray-major [fs*fs, C]: transposed once per parameter
         version into a buffer whose address never changes (recorded graphs read it)."""
@@ -414,6 +461,7 @@ class HeadNeRFNet(nn.Module):
             dst = c[1] if c is not None and c[1].device == bg.device else torch.empty(fs * fs, C, dtype=torch.float32, device=bg.device)
             ops.chw_to_hwc(bg.detach().view(C, fs * fs), C, fs * fs, dst)
             self._bg_cache = c = (ver, dst)
+            self._bg_serial = getattr(self, "_bg_serial", 0) + 1  # moves with every re-transpose (what the batch buffers compare)
         return c[1]
 
     def invalidate_packed(self):
@@ -422,9 +470,14 @@ class HeadNeRFNet(nn.Module):
         `load_state_dict` all move; writes through `.data` (the reference's own `load_ckpt` does
         `model.state_dict()[k].data.copy_(v)`, talker_trainer.py:557-567) do NOT move them -- call this after such a
         write, or use n3dt.checkpoint.load_ckpt, which does."""
-        self._pack_cache.clear()
-        self._bg_cache = None
-        self._maps_cache.clear()
+        # the BUFFERS stay (recorded hipGraphs hold their addresses; the next call re-packs / re-transposes into them in
+        # place, stream-ordered); only the versions they were made from are forgotten
+        for k, (ver, buf) in list(self._pack_cache.items()):
+            self._pack_cache[k] = (None, buf)
+        if self._bg_cache is not None:
+            self._bg_cache = (None, self._bg_cache[1])
+        for k, ent in list(self._maps_cache.items()):
+            self._maps_cache[k] = (None,) + tuple(ent[1:])
         self.neural_render.invalidate_packed()
         for e in self._graphs.values():
             e["bg_ver"] = None
@@ -483,6 +536,9 @@ class HeadNeRFNet(nn.Module):
             # re-pack INTO the existing buffer (stream-ordered): recorded hipGraphs keep reading a valid address
             hit = (ver, ops.pack_mlp(geom, precision, params, ws[0].device, out=None if hit is None else hit[1]))
             self._pack_cache[key] = hit
+            if len(self._pack_cache) > 16:  # stale keys (parameters re-allocated by .to() / a new dtype) do not pile up
+                for k in [k for k in self._pack_cache if k != key][:len(self._pack_cache) - 16]:
+                    del self._pack_cache[k]
         return hit[1]
 
     def render_features(self, batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
@@ -549,18 +605,21 @@ class HeadNeRFNet(nn.Module):
         return self._result(imgs, batch_size, nb)
 
     def _maps_with_background(self, nb, dev):
-        """The renderer's input batch [nb + 1, fs, fs, C] (merged maps, then the background map) as scratch kept per (nb, device,
-        stream): the background slot is filled once per parameter version instead of by a copy kernel in every forward (it is 4 us
-        of a 0.64 ms one-head step).  The merged slots are overwritten by every call; the images returned to the caller are separate."""
+        """The renderer's input batch [nb + 1, fs, fs, C] (merged maps, then the background map) as scratch kept per (device,
+        stream), grow-only: the background slot is filled once per parameter version and batch size instead of by a copy
+        kernel in every forward (it is 4 us of a 0.64 ms one-head step).  The merged slots are overwritten by every call; the
+        images returned to the caller are separate."""
         bg = self._bg_hwc()
-        key = (nb, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
         ent = self._maps_cache.get(key)
-        if ent is None or ent[0] != self._bg_cache[0]:
-            fs, C = self.featmap_size, self.featmap_nc
-            maps = ent[1] if ent is not None else torch.empty(nb + 1, fs, fs, C, dtype=torch.float32, device=dev)
-            maps[nb].view(fs * fs, C).copy_(bg)
-            self._maps_cache[key] = ent = (self._bg_cache[0], maps)
-        return ent[1]
+        fs, C = self.featmap_size, self.featmap_nc
+        if ent is None or ent[1].shape[0] < nb + 1:
+            ent = (None, torch.empty(nb + 1, fs, fs, C, dtype=torch.float32, device=dev))
+        tag = (self._bg_serial, nb)
+        if ent[0] != tag:
+            ent[1][nb].view(fs * fs, C).copy_(bg)
+            self._maps_cache[key] = ent = (tag, ent[1])
+        return ent[1][:nb + 1]
 
     def _result(self, imgs, batch_size, nb):
         res = {"coarse_dict": {"merge_img": imgs[:batch_size], "bg_img": imgs[nb:]}}
@@ -618,10 +677,15 @@ class HeadNeRFNet(nn.Module):
             if len(self._graphs) >= 8:  # a handful of call shapes per model in practice; do not grow without bound
                 self._drop_graph(self._graphs.pop(next(iter(self._graphs))))
             e = self._graphs[key] = self._record_graph(B, n_r, dev, sig, xy, small)
-        # packed weights follow the parameters' version counters; re-packed in place, so the recorded address stays valid
+        # packed weights follow the parameters' version counters; re-packed in place, so the recorded address stays valid.
+        # Should an address differ all the same (the buffer was replaced behind the graph's back), the graph is recorded again.
         for fine in ((False, True) if self.hier_sampling else (False,)):
             params, ws, bs = self._mlp_params(fine=fine)
-            assert self._packed(e["geom"], _lib.PRECISIONS[self.precision], params, ws, bs).data_ptr() == e["packed"][fine]
+            if self._packed(e["geom"], _lib.PRECISIONS[self.precision], params, ws, bs).data_ptr() != e["packed"][fine] or \
+                    self._bg_hwc().data_ptr() != e["bg_ptr"]:
+                self._drop_graph(self._graphs.pop(key))
+                e = self._graphs[key] = self._record_graph(B, n_r, dev, sig, xy, small)
+                break
         self._refresh_graph_constants(e)
         ops.stage_inputs([(xy, e["xy"])] + list(zip(small, e["small"])), view=xy)
         ops.graph_launch(e["graph"])
@@ -662,7 +726,7 @@ class HeadNeRFNet(nn.Module):
             params, ws, bs = self._mlp_params(fine=fine)
             packed[fine] = self._packed(geom, prec, params, ws, bs).data_ptr()  # packs now, on the caller's stream
         e["packed"], e["bufs"] = packed, bufs
-        self._bg_hwc()
+        e["bg_ptr"] = self._bg_hwc().data_ptr()
         self._refresh_graph_constants(e)
         R, T, Kinv, shape, appea = e["small"][:5]
         audio = e["small"][5] if self.audio_dim > 0 else None
@@ -673,8 +737,13 @@ class HeadNeRFNet(nn.Module):
             ops.graph_begin(side)
             try:
                 self._infer_launch(e["xy"], audio, shape, appea, R, T, Kinv, None, None, e["maps"], imgs=e["imgs"], bufs=bufs)
-            finally:
-                e["graph"] = ops.graph_end(side)
+            except BaseException:
+                try:  # end the capture so the stream is usable again, and let the ORIGINAL error through
+                    ops.graph_destroy(ops.graph_end(side))
+                except Exception:
+                    pass
+                raise
+            e["graph"] = ops.graph_end(side)
         return e
 
     def _drop_graph(self, e):

@@ -32,6 +32,58 @@ def rank_env(rank, world, port, base=None):
     return env
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(index, sysfs="/sys/bus/pci/drivers/amdgpu"):
+    """CPUs of the NUMA node GPU `index` hangs off (sysfs `local_cpulist` of the index-th amdgpu PCI function in bus order,
+    after HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES re-indexing when those are plain integer lists), or None when unknown."""
+    try:
+        devs = sorted(d for d in os.listdir(sysfs) if d.count(":") == 2)
+    except OSError:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        vis = os.environ.get(var)
+        if vis:
+            try:
+                devs = [devs[int(v)] for v in vis.split(",")]
+            except (ValueError, IndexError):
+                return None
+    if not 0 <= index < len(devs):
+        return None
+    try:
+        with open(os.path.join(sysfs, devs[index], "local_cpulist")) as f:
+            return _parse_cpulist(f.read()) or None
+    except (OSError, ValueError):
+        return None
+
+
+def bind_rank_to_gpu_numa(local_rank):
+    """Pin this process to the CPUs next to its GPU (host-side launch latency and the pinned-memory path both cross the socket
+    interconnect otherwise).  Only ever narrows the current affinity mask; does nothing when the topology is unknown, when the
+    intersection is empty, or when N3DT_NO_AFFINITY=1.  Returns the CPU count bound to, or None."""
+    if os.environ.get("N3DT_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    local = gpu_local_cpus(local_rank)
+    if not local:
+        return None
+    want = os.sched_getaffinity(0) & local
+    if not want:
+        return None
+    try:
+        os.sched_setaffinity(0, want)
+    except OSError:
+        return None
+    return len(want)
+
+
 def spawn_ranks(argv, world, env=None, timeout=None, poll_s=0.2):
     """Run `sys.executable argv...` as `world` ranks; rank 0 inherits stdout.  Returns the first non-zero exit
     code (the other ranks are then terminated by PID), 0 when every rank succeeded, 124 on timeout."""

@@ -306,13 +306,14 @@ def render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape, appea, audio, 
     return out, saved
 
 
-def render_bwd(geom, params, grads, shape, appea, audio, bg_featmap, d_merge, saved, cam=None, precision=0):
+def render_bwd(geom, params, grads, shape, appea, audio, bg_featmap, d_merge, saved, cam=None, precision=0, d_bg=None):
     """Backward of render_train_fwd.  `grads` (MlpParams struct of zeroed tensors) is accumulated into.
     cam = (xy, R, T, Kinv, t_rand) requests camera gradients.
     Returns (d_bg_featmap [C,Nr], d_shape, d_appea, d_audio, d_R, d_T)."""
     dev = d_merge.device
     B, Nr, C = geom.batch, geom.n_rays, geom.feat_nc
-    d_bg = torch.zeros(C, Nr, dtype=torch.float32, device=dev)
+    if d_bg is None:  # (a caller-provided buffer -- a slice of the gradient arena -- is already zeroed)
+        d_bg = torch.zeros(C, Nr, dtype=torch.float32, device=dev)
     d_shape = torch.empty(B, geom.shape_dim, dtype=torch.float32, device=dev)
     d_appea = torch.empty(B, geom.appea_dim, dtype=torch.float32, device=dev)
     d_audio = torch.empty(B, geom.audio_dim, dtype=torch.float32, device=dev) if geom.audio_dim > 0 else None

@@ -41,7 +41,7 @@ def _worker(rank, world, port, total_frames, out):
     loss.backward()
     parallel.allreduce_gradients(net.parameters())
     if rank == 0:
-        out.put([p.grad.clone() for p in net.parameters()])
+        out.put([p.grad.tolist() for p in net.parameters()])  # plain lists: nothing of the sender must outlive the put
     # the timing protocol of bench.py: barrier, then MAX of the per-rank elapsed time
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.barrier()
@@ -63,13 +63,29 @@ def test_shard_range_covers_everything():
 
 def test_two_rank_gradient_average_equals_full_batch():
     world, total = 2, 8  # equal shards: mean of shard means == full-batch mean
+    import queue
+    import time
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get()
+    # bounded wait for rank 0's answer: a rank that dies before answering (import error, failed rendezvous) must fail the
+    # test, not hang the suite.  (Round 2 tried `while q.empty()` on a SimpleQueue and reverted it: SimpleQueue.empty() polls
+    # the pipe without the reader lock and raced with get() under spawn; mp.Queue.get(timeout) is the supported form.)
+    got, deadline = None, time.time() + 600
+    while got is None:
+        try:
+            got = q.get(timeout=1.0)
+        except queue.Empty:
+            codes = [p.exitcode for p in procs]
+            if any(c not in (None, 0) for c in codes) or time.time() > deadline:
+                for p in procs:
+                    if p.exitcode is None:
+                        p.kill()
+                pytest.fail("ranks did not answer: exit codes %s" % codes)
+    got = [torch.tensor(g) for g in got]
     for p in procs:
         p.join(timeout=600)  # a cold `import torch` in a freshly spawned interpreter can take minutes on a busy machine
         if p.exitcode is None:
