@@ -237,7 +237,7 @@ def run_train(ctx, config, train_precision, batch, steps, warmup, audio2style_bu
         pred_ = net("train", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"],
                     d["batch_Rmats"], d["batch_Tvecs"], d["batch_inv_inmats"])
         t = data_losses(pred_["coarse_dict"], gt, mask)
-        loss = t["bg_loss"] + t["head_loss"] + t["nonhead_loss"]
+        loss = t["total_loss"]   # (bg + head) + nonhead, formed by the loss kernel
         optim.zero_grad()
         loss.backward()
         if bucket is not None:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define N3DT_ABI_VERSION 3
+#define N3DT_ABI_VERSION 4
 
 /* arithmetic type of the MLP contraction */
 #define N3DT_F32 0  /* v_mfma_f32_16x16x4_f32, exact fp32: the <=1e-3 RGB parity mode */
@@ -259,12 +259,14 @@ int n3dt_img_to_uint8(int n_images, int pixels, const float* img, unsigned char*
  * The three MSE data terms of the reference's loss (Utils/HeadNeRFLossUtils.py:125-146: bg_loss, head_loss,
  * nonhead_loss, including its nan_to_num) in one pass, and their gradient in one more; replaces three boolean-mask
  * gathers.  merge_img, gt [B,3,P,P]; bg_img [1,3,P,P]; mask [B,1,P,P] (head where >= 0.5); pixels = P*P.
- * n3dt_loss_fwd writes terms[3] = {bg, head, nonhead} and keeps its sums/counts in acc[6] for n3dt_loss_bwd, which
- * takes the upstream gradients g[3] of the three terms and writes d_merge [B,3,P,P] and d_bg [1,3,P,P]. */
+ * n3dt_loss_fwd writes terms[4] = {bg, head, nonhead, (bg + head) + nonhead -- the reference's total, :228-231} and keeps
+ * its sums/counts in acc[8] for n3dt_loss_bwd, which takes the upstream gradients g[3] of the three terms and / or g_total[1]
+ * of their sum (each nullable, not both) and writes d_merge [B,3,P,P] and d_bg [1,3,P,P].  (ABI 4: acc grew from 6 to 8
+ * floats, terms from 3 to 4, g_total is new.) */
 int n3dt_loss_fwd(int batch, int pixels, const float* merge_img, const float* bg_img, const float* gt, const float* mask,
                   float bg_value, float* acc, float* terms, void* stream);
 int n3dt_loss_bwd(int batch, int pixels, const float* merge_img, const float* bg_img, const float* gt, const float* mask,
-                  float bg_value, const float* acc, const float* g, float* d_merge, float* d_bg, void* stream);
+                  float bg_value, const float* acc, const float* g, const float* g_total, float* d_merge, float* d_bg, void* stream);
 
 /* [C, N_r] (NCHW parameter) -> [N_r, C]; used to feed bg_featmap to the renderer */
 int n3dt_chw_to_hwc(int C, int n, const float* src, float* dst, void* stream);

@@ -56,7 +56,7 @@ void n3dt_launch_train16_bwd(const N3dtGeom*, const N3dtMlpParams*, const N3dtMl
                              const float*, const float*, const float*, const float*, const float*, float*, float*, void*, hipStream_t);
 void n3dt_launch_img_to_uint8(int, int, const float*, unsigned char*, hipStream_t);
 void n3dt_launch_loss_fwd(int, int, const float*, const float*, const float*, const float*, float, float*, float*, hipStream_t);
-void n3dt_launch_loss_bwd(int, int, const float*, const float*, const float*, const float*, float, const float*, const float*, float*,
+void n3dt_launch_loss_bwd(int, int, const float*, const float*, const float*, const float*, float, const float*, const float*, const float*, float*,
                           float*, hipStream_t);
 size_t n3dt_nr_train_saved_floats(const N3dtGeom*, int);
 size_t n3dt_nr_train_ws_floats(const N3dtGeom*, int);
@@ -487,10 +487,10 @@ extern "C" int n3dt_loss_fwd(int batch, int pixels, const float* merge_img, cons
 }
 
 extern "C" int n3dt_loss_bwd(int batch, int pixels, const float* merge_img, const float* bg_img, const float* gt, const float* mask,
-                             float bg_value, const float* acc, const float* g, float* d_merge, float* d_bg, void* stream) {
-    if (batch < 1 || pixels < 1 || !merge_img || !bg_img || !gt || !mask || !acc || !g || !d_merge || !d_bg)
+                             float bg_value, const float* acc, const float* g, const float* g_total, float* d_merge, float* d_bg, void* stream) {
+    if (batch < 1 || pixels < 1 || !merge_img || !bg_img || !gt || !mask || !acc || (!g && !g_total) || !d_merge || !d_bg)
         return fail(N3DT_EINVAL, "n3dt_loss_bwd: bad argument");
-    n3dt_launch_loss_bwd(batch, pixels, merge_img, bg_img, gt, mask, bg_value, acc, g, d_merge, d_bg, (hipStream_t)stream);
+    n3dt_launch_loss_bwd(batch, pixels, merge_img, bg_img, gt, mask, bg_value, acc, g, g_total, d_merge, d_bg, (hipStream_t)stream);
     return check_hip("n3dt_loss_bwd");
 }
 

@@ -117,7 +117,7 @@ def lib():
     L.n3dt_loss_fwd.restype = ci
     L.n3dt_loss_fwd.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp]
     L.n3dt_loss_bwd.restype = ci
-    L.n3dt_loss_bwd.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, vp]
+    L.n3dt_loss_bwd.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, vp, vp]
     L.n3dt_prof_enable.restype = ci
     L.n3dt_prof_enable.argtypes = [ci]
     L.n3dt_prof_collect.restype = ci
@@ -146,7 +146,7 @@ def lib():
     L.n3dt_graph_launch.argtypes = [vp, vp]
     L.n3dt_graph_destroy.restype = ci
     L.n3dt_graph_destroy.argtypes = [vp]
-    if L.n3dt_abi_version() != 3:
+    if L.n3dt_abi_version() != 4:
         raise N3dtError("libn3dt.so ABI version mismatch")
     _LIB = L
     return L

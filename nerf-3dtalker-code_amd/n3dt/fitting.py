@@ -69,7 +69,7 @@ def fit_step(net, state, optimizer, scheduler, batch_xy, batch_uv, audiostyle, g
     with torch.set_grad_enabled(True):
         pred = net("test", batch_xy, batch_uv, audiostyle, **code_info, **cam_info)
         terms = loss_fn(pred["coarse_dict"], gt_rgb, mask)
-        total = terms["bg_loss"] + terms["head_loss"] + terms["nonhead_loss"]
+        total = terms["total_loss"] if "total_loss" in terms else terms["bg_loss"] + terms["head_loss"] + terms["nonhead_loss"]
     optimizer.zero_grad()
     total.backward()
     optimizer.step()

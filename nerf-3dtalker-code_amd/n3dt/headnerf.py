@@ -158,7 +158,7 @@ class NeuralRenderer(nn.Module):
         flat = []
         for m in self._flat_modules():
             flat += [m.weight, m.bias]
-        return _NeuralRenderFn.apply(self, featmap_hwc, *flat)
+        return _NeuralRenderFn.apply(self, None, 0, featmap_hwc, None, *flat)
 
     def _param_sig(self):
         return tuple((p.data_ptr(), p._version) for m in self._flat_modules() for p in (m.weight, m.bias))
@@ -237,7 +237,10 @@ class _RenderFn(torch.autograd.Function):
     24 MLP parameter tensors (all differentiable; R/T gradients are computed only when they require grad)."""
 
     @staticmethod
-    def forward(ctx, net, geom, xy, Kinv, t_rand, R, T, shape, appea, audio, bg_featmap, *mlp):
+    def forward(ctx, net, geom, merge_out, xy, Kinv, t_rand, R, T, shape, appea, audio, bg_featmap, *mlp):
+        """merge_out: None, or a _Slot whose `.t` [B, N_r, C] (a slice of the renderer's input batch) receives the merged
+        map and becomes the output.  (Handed over inside a plain object, not as a tensor argument: autograd then sees a fresh
+        output, not a modified input.)"""
         ctx.want_cam = R.requires_grad or T.requires_grad
         ctx.T_shape = T.shape
         R = ops._f32c(R)
@@ -247,11 +250,15 @@ class _RenderFn(torch.autograd.Function):
         params = ops.mlp_params(ws, bs)
         # "bf16" = the fused mixed-precision path (bf16 MFMA products, fp32 parameters and gradients)
         ctx.prec = _lib.PRECISIONS[net.train_precision]
-        packed = net._packed(geom, ctx.prec, params, ws, bs)
+        # Weights under training change every step, and not every optimizer moves the version counters the packed-weight cache
+        # follows: torch.optim.Adam(fused=True) updates the parameters WITHOUT bumping `_version` (seen: one pack in 13 steps).
+        # So the differentiable path re-packs whenever a weight requires grad (two small launches, in place).
+        packed = net._packed(geom, ctx.prec, params, ws, bs, force=any(t.requires_grad for t in mlp))
         shape_c, appea_c = ops._f32c(shape), ops._f32c(appea)
         audio_c = ops._f32c(audio) if geom.audio_dim > 0 else None
         bg = bg_featmap.detach().reshape(geom.feat_nc, -1).contiguous()
-        out, saved = ops.render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape_c, appea_c, audio_c, t_rand, bg, ctx.prec)
+        out, saved = ops.render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape_c, appea_c, audio_c, t_rand, bg, ctx.prec,
+                                          merge_out=None if merge_out is None else merge_out.t)
         ctx.geom, ctx.saved, ctx.keep = geom, saved, (ws, bs, shape_c, appea_c, audio_c, bg)
         ctx.cam = (xy, R, T, Kinv, t_rand) if ctx.want_cam else None
         ctx.bg_shape = bg_featmap.shape
@@ -277,40 +284,114 @@ class _RenderFn(torch.autograd.Function):
         ctx.saved = None
         grads = [g.view(s) for g, s in zip(gws + gbs, ctx.mlp_shapes)]
         del gws, gbs, views, d_bg_out  # the returned views must be the only references (autograd then adopts them as .grad)
+        if any(ctx.needs_input_grad[12:]) or ctx.needs_input_grad[11]:
+            # parameter gradients went out: an optimizer step follows, possibly one that leaves the version counters alone
+            # (fused Adam) -- void every packed / transposed copy so the next forward of any kind rebuilds them
+            ctx.net.invalidate_packed()
         if d_T is not None:
             d_T = d_T.view(ctx.T_shape)
-        return (None, None, None, None, None, d_R, d_T, d_shape, d_appea, d_audio, d_bg.view(ctx.bg_shape), *grads)
+        return (None, None, None, None, None, None, d_R, d_T, d_shape, d_appea, d_audio, d_bg.view(ctx.bg_shape), *grads)
+
+
+class _Slot:
+    """A tensor handed to an autograd Function outside its tensor arguments (see _RenderFn.forward)."""
+
+    def __init__(self, t):
+        self.t = t
+
+
+def _adjacent(parts):
+    """parts: contiguous tensors (or None).  The one tensor [sum of leading dims, ...] they form when they are consecutive
+    slices of one allocation, else None."""
+    if any(p is None or not p.is_contiguous() for p in parts):
+        return None
+    p0 = parts[0]
+    off = p0.storage_offset()
+    for p in parts:
+        if p.untyped_storage().data_ptr() != p0.untyped_storage().data_ptr() or p.storage_offset() != off or \
+                p.shape[1:] != p0.shape[1:] or p.dtype != p0.dtype:
+            return None
+        off += p.numel()
+    n = sum(p.shape[0] for p in parts)
+    return torch.as_strided(p0, (n,) + tuple(p0.shape[1:]), p0.stride(), p0.storage_offset())
 
 
 class _NeuralRenderFn(torch.autograd.Function):
-    """a8..a10 with saved activations and the hand-written backward (n3dt_neural_render_bwd)."""
+    """a8..a10 with saved activations and the hand-written backward (n3dt_neural_render_bwd).
+
+    Two call shapes.  (1) `apply(nr, None, 0, featmap, None, *flat)`: featmap [nb, fs, fs, C] -> img [nb, 3, P, P] (the
+    module's own forward()).  (2) HeadNeRFNet's training step, `apply(nr, maps, n_split, merged, bg_featmap, *flat)`: `maps`
+    (a _Slot) is the renderer's whole input batch [nb + 1, fs, fs, C]; its first nb maps were written in place by the
+    _RenderFn calls whose outputs `merged` (a tuple of [B, N_r, C] slices of it, concatenated by construction) are; the last
+    slot is filled here from bg_featmap [1, C, fs, fs] (one transposing launch).  Outputs: the merged images and the
+    background image as separate tensors (slices of one buffer) -- no torch.cat on the way in, no slice-backward
+    zeros + copy + add on the way out."""
 
     @staticmethod
-    def forward(ctx, nr, featmap, *flat):
-        nb = featmap.shape[0]
+    def forward(ctx, nr, maps, n_merged, featmap, bg_featmap, *rest):
+        merged, flat = rest[:n_merged], rest[n_merged:]
+        if maps is None:
+            fm = featmap.detach().contiguous()
+            nb = fm.shape[0]
+        else:
+            fm = maps.t
+            nb = fm.shape[0]
+            fs, C = nr.featmap_size, nr.n_feat
+            off = fm.storage_offset()
+            for m in merged:  # the slices _RenderFn wrote
+                assert m.untyped_storage().data_ptr() == fm.untyped_storage().data_ptr() and m.storage_offset() == off
+                off += m.numel()
+            assert off == fm.storage_offset() + (nb - 1) * fs * fs * C
+            ops.chw_to_hwc(bg_featmap.detach().reshape(C, fs * fs), C, fs * fs, fm[nb - 1].view(fs * fs, C))
         geom = nr._geom(nb)
         tensors = [t.detach().view(t.shape[0], -1).contiguous() if t.dim() == 4 else t.detach().contiguous() for t in flat]
         rp = nr._rparams_from(tensors)
-        fm = featmap.detach().contiguous()
         ctx.prec = _lib.PRECISIONS[nr.train_precision]
         img, saved = ops.neural_render_train_fwd(geom, nb, rp, fm, ctx.prec)
         ctx.nr, ctx.geom, ctx.nb, ctx.saved, ctx.keep = nr, geom, nb, saved, (tensors, fm)
         ctx.shapes = [t.shape for t in flat]
         ctx.param_objs = list(flat)
-        return img
+        ctx.split = None if maps is None else [m.shape[0] for m in merged]
+        ctx.merged_shapes = [m.shape for m in merged]
+        ctx.set_materialize_grads(False)
+        if maps is None:
+            return img
+        outs, lo = [], 0
+        for n in ctx.split:
+            outs.append(img[lo:lo + n])
+            lo += n
+        return (*outs, img[lo:])
 
     @staticmethod
-    def backward(ctx, d_img):
+    def backward(ctx, *d_imgs):
         tensors, fm = ctx.keep
+        nb = ctx.nb
+        P = d_imgs[0].shape[-1] if d_imgs[0] is not None else (ctx.nr.featmap_size << ctx.nr.n_blocks)
+        if ctx.split is None:
+            d_img = d_imgs[0].contiguous()
+        else:
+            d_img = _adjacent(d_imgs)  # the fused loss tail returns them as consecutive slices of one buffer
+            if d_img is None:
+                sizes = ctx.split + [1]
+                d_img = torch.cat([torch.zeros(n, 3, P, P, dtype=torch.float32, device=fm.device) if d is None else d.float()
+                                   for d, n in zip(d_imgs, sizes)])
         owner = ctx.nr._arena_owner
         views = owner._hand_out_grads(ctx.param_objs) if owner is not None else None
         gt = _zeros_like_many(list(tensors)) if views is None else [v.view(t.shape) for v, t in zip(views, tensors)]
-        d_feat = ops.neural_render_bwd(ctx.geom, ctx.nb, ctx.nr._rparams_from(tensors), ctx.nr._rparams_from(gt), fm,
-                                       d_img.contiguous(), ctx.saved, ctx.prec)
+        d_feat = ops.neural_render_bwd(ctx.geom, nb, ctx.nr._rparams_from(tensors), ctx.nr._rparams_from(gt), fm,
+                                       d_img, ctx.saved, ctx.prec)
         ctx.saved = None
         grads = [g.view(s) for g, s in zip(gt, ctx.shapes)]
         del gt, views
-        return (None, d_feat, *grads)
+        if ctx.split is None:
+            return (None, None, None, d_feat, None, *grads)
+        fs, C = ctx.nr.featmap_size, ctx.nr.n_feat
+        d_merged, lo = [], 0
+        for n, shp in zip(ctx.split, ctx.merged_shapes):
+            d_merged.append(d_feat[lo:lo + n].view(shp))
+            lo += n
+        d_bg = ops.chw_to_hwc(d_feat[nb - 1].view(fs * fs, C), fs * fs, C).view(1, C, fs, fs)  # [N_r, C] -> [C, N_r]
+        return (None, None, None, None, d_bg, *d_merged, *grads)
 
 
 class FineSample(nn.Module):
@@ -527,12 +608,12 @@ class HeadNeRFNet(nn.Module):
         bs = [m.bias.detach() for m in layers]
         return ops.mlp_params(ws, bs), ws, bs
 
-    def _packed(self, geom, precision, params, ws, bs):
+    def _packed(self, geom, precision, params, ws, bs, force=False):
         """Packed weights, re-packed whenever the optimizer (or a load) touched a parameter."""
         key = (precision, ws[0].device.index, ws[0].data_ptr())
         ver = tuple((t.data_ptr(), t._version) for t in ws + bs)
         hit = self._pack_cache.get(key)
-        if hit is None or hit[0] != ver:
+        if hit is None or hit[0] != ver or force:
             # re-pack INTO the existing buffer (stream-ordered): recorded hipGraphs keep reading a valid address
             hit = (ver, ops.pack_mlp(geom, precision, params, ws[0].device, out=None if hit is None else hit[1]))
             self._pack_cache[key] = hit
@@ -774,9 +855,15 @@ class HeadNeRFNet(nn.Module):
         layers = self.fg_CD_predictor.layers()
         mlp = [m.weight for m in layers] + [m.bias for m in layers]
         audio = audiostyle if self.audio_dim > 0 else torch.zeros(B, 0, device=xy.device)
-        merge = _RenderFn.apply(self, geom, xy.detach(), ops._f32c(batch_inv_inmats), None if t_rand is None else ops._f32c(t_rand),
+        n_pass = 2 if self.hier_sampling else 1
+        nb = B * n_pass
+        # the renderer's input batch, allocated per call (it is saved for the backward): the volumetric passes write their merged
+        # maps straight into it, the renderer's forward fills the last slot from bg_featmap
+        maps = torch.empty(nb + 1, fs, fs, C, dtype=torch.float32, device=xy.device)
+        Kinv = ops._f32c(batch_inv_inmats)
+        merge = _RenderFn.apply(self, geom, _Slot(maps[:B].view(B, n_r, C)), xy.detach(), Kinv, None if t_rand is None else ops._f32c(t_rand),
                                 batch_Rmats, batch_Tvecs, shape_code, appea_code, audio, self.neural_render.bg_featmap, *mlp)
-        passes = [merge.view(B, fs, fs, C)]
+        merged = [merge]
         if self.hier_sampling:
             with torch.no_grad():
                 w = self.render_features(batch_xy, audiostyle, shape_code, appea_code, batch_Rmats, batch_Tvecs, batch_inv_inmats,
@@ -787,15 +874,15 @@ class HeadNeRFNet(nn.Module):
             gfine = self._geom(B, n_r, xy, n_samples=planes.shape[-1] - 1, z_planes_given=1)
             flayers = self.fine_fg_CD_predictor.layers()
             fmlp = [m.weight for m in flayers] + [m.bias for m in flayers]
-            fmerge = _RenderFn.apply(self, gfine, xy.detach(), ops._f32c(batch_inv_inmats), planes, batch_Rmats, batch_Tvecs, shape_code,
-                                     appea_code, audio, self.neural_render.bg_featmap, *fmlp)
-            passes.append(fmerge.view(B, fs, fs, C))
-        bg_hwc = self.neural_render.bg_featmap.view(C, fs * fs).t().reshape(1, fs, fs, C)
-        nb = B * len(passes)
-        imgs = self.neural_render.render_hwc_train(torch.cat(passes + [bg_hwc], dim=0))
-        res = {"coarse_dict": {"merge_img": imgs[:B], "bg_img": imgs[nb:]}}
+            merged.append(_RenderFn.apply(self, gfine, _Slot(maps[B:nb].view(B, n_r, C)), xy.detach(), Kinv, planes, batch_Rmats, batch_Tvecs,
+                                          shape_code, appea_code, audio, self.neural_render.bg_featmap, *fmlp))
+        flat = []
+        for m in self.neural_render._flat_modules():
+            flat += [m.weight, m.bias]
+        imgs = _NeuralRenderFn.apply(self.neural_render, _Slot(maps), len(merged), None, self.neural_render.bg_featmap, *merged, *flat)
+        res = {"coarse_dict": {"merge_img": imgs[0], "bg_img": imgs[-1]}}
         if self.hier_sampling:
-            res["fine_dict"] = {"merge_img": imgs[B:nb], "bg_img": imgs[nb:]}
+            res["fine_dict"] = {"merge_img": imgs[1], "bg_img": imgs[-1]}
         return res
 
     def forward(self, mode, batch_xy, batch_uv, audiostyle=None, bg_code=None, shape_code=None, appea_code=None,

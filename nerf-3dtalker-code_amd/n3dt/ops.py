@@ -286,14 +286,17 @@ def _bytes_or_raise(n, what):
     return n
 
 
-def render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap, precision=0):
-    """Forward with saved activations.  `packed` = pack_mlp(...) of the same precision.  Returns (out dict, saved buffer)."""
+def render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap, precision=0, merge_out=None):
+    """Forward with saved activations.  `packed` = pack_mlp(...) of the same precision.  Returns (out dict, saved buffer).
+    merge_out: caller-owned [B, N_r, C] buffer for the merged map (a slice of the renderer's input batch)."""
     dev = xy.device
     B, Nr, C = geom.batch, geom.n_rays, geom.feat_nc
+    if merge_out is not None:
+        assert merge_out.is_contiguous() and tuple(merge_out.shape) == (B, Nr, C) and merge_out.dtype == torch.float32
     out = {
         "fg_feat": torch.empty(B, Nr, C, dtype=torch.float32, device=dev),
         "bg_alpha": torch.empty(B, Nr, dtype=torch.float32, device=dev),
-        "merge_feat": torch.empty(B, Nr, C, dtype=torch.float32, device=dev),
+        "merge_feat": merge_out if merge_out is not None else torch.empty(B, Nr, C, dtype=torch.float32, device=dev),
     }
     sbytes = _bytes_or_raise(lib().n3dt_render_train_saved_bytes(ctypes.byref(geom)), "n3dt_render_train_saved_bytes")
     wbytes = _bytes_or_raise(lib().n3dt_render_train_workspace_bytes(ctypes.byref(geom)), "n3dt_render_train_workspace_bytes")
@@ -314,9 +317,12 @@ def render_bwd(geom, params, grads, shape, appea, audio, bg_featmap, d_merge, sa
     B, Nr, C = geom.batch, geom.n_rays, geom.feat_nc
     if d_bg is None:  # (a caller-provided buffer -- a slice of the gradient arena -- is already zeroed)
         d_bg = torch.zeros(C, Nr, dtype=torch.float32, device=dev)
-    d_shape = torch.empty(B, geom.shape_dim, dtype=torch.float32, device=dev)
-    d_appea = torch.empty(B, geom.appea_dim, dtype=torch.float32, device=dev)
-    d_audio = torch.empty(B, geom.audio_dim, dtype=torch.float32, device=dev) if geom.audio_dim > 0 else None
+    # the three code gradients side by side in one allocation: the library zeroes adjacent buffers with one launch
+    S_, A_, U_ = geom.shape_dim, geom.appea_dim, geom.audio_dim
+    codes = torch.empty(B * (S_ + A_ + U_), dtype=torch.float32, device=dev)
+    d_shape = codes[:B * S_].view(B, S_)
+    d_appea = codes[B * S_:B * (S_ + A_)].view(B, A_)
+    d_audio = codes[B * (S_ + A_):].view(B, U_) if U_ > 0 else None
     d_R = d_T = None
     cam_ptrs = [None] * 5
     if cam is not None:

@@ -31,7 +31,10 @@ def data_losses(coarse, gt_rgb, mask, bg_value=1.0):
 
 
 class _FusedDataLoss(torch.autograd.Function):
-    """bg / head / nonhead MSE terms in one pass over the images (n3dt_loss_fwd / n3dt_loss_bwd)."""
+    """bg / head / nonhead MSE terms and their sum in one pass over the images (n3dt_loss_fwd / n3dt_loss_bwd).
+    Four scalar outputs (views of one 4-float buffer): indexing ONE output tensor instead cost the step a zeros + copy + add
+    chain per term in backward.  The two image gradients are slices of one buffer, merged images first, so that the
+    renderer's backward finds them adjacent and takes them as its d_img without a concatenation."""
 
     @staticmethod
     def forward(ctx, merge_img, bg_img, gt_rgb, mask, bg_value):
@@ -50,31 +53,40 @@ class _FusedDataLoss(torch.autograd.Function):
         if not (merge_img.is_cuda and all(t.device == merge_img.device for t in (bg_img, gt_rgb, mask))):
             raise ValueError("fused_data_losses: all tensors must live on the same GPU (no CPU fallback)")
         m, b, g, k = (t.detach().float().contiguous() for t in (merge_img, bg_img, gt_rgb, mask))
-        acc = torch.empty(6, dtype=torch.float32, device=m.device)
-        terms = torch.empty(3, dtype=torch.float32, device=m.device)
+        acc = torch.empty(8, dtype=torch.float32, device=m.device)
+        terms = torch.empty(4, dtype=torch.float32, device=m.device)
         check(lib().n3dt_loss_fwd(B, P * Q, ops._ptr(m), ops._ptr(b), ops._ptr(g), ops._ptr(k), ctypes.c_float(bg_value),
                                   ops._ptr(acc), ops._ptr(terms), ops._stream()), "n3dt_loss_fwd")
         ctx.keep, ctx.bg_value = (m, b, g, k, acc), bg_value
-        return terms
+        ctx.set_materialize_grads(False)
+        return terms[0], terms[1], terms[2], terms[3]
 
     @staticmethod
-    def backward(ctx, g_terms):
+    def backward(ctx, g_bg, g_head, g_non, g_total):
         import ctypes
         from . import ops
         from ._lib import lib, check
         m, b, g, k, acc = ctx.keep
         B, _, P, Q = m.shape
-        d_m, d_b = torch.empty_like(m), torch.zeros_like(b)
+        if g_bg is None and g_head is None and g_non is None and g_total is None:
+            return None, None, None, None, None
+        g3 = None
+        if g_bg is not None or g_head is not None or g_non is not None:
+            z = torch.zeros((), dtype=torch.float32, device=m.device)
+            g3 = torch.stack([z if t is None else t.float() for t in (g_bg, g_head, g_non)])
+        gt_ = None if g_total is None else g_total.float().contiguous()
+        d_all = torch.empty(B + 1, 3, P, Q, dtype=torch.float32, device=m.device)  # [merge images..., background image]
         check(lib().n3dt_loss_bwd(B, P * Q, ops._ptr(m), ops._ptr(b), ops._ptr(g), ops._ptr(k), ctypes.c_float(ctx.bg_value),
-                                  ops._ptr(acc), ops._ptr(g_terms.float().contiguous()), ops._ptr(d_m), ops._ptr(d_b),
+                                  ops._ptr(acc), ops._ptr(g3), ops._ptr(gt_), ops._ptr(d_all[:B]), ops._ptr(d_all[B:]),
                                   ops._stream()), "n3dt_loss_bwd")
-        return d_m, d_b, None, None, None
+        return d_all[:B], d_all[B:], None, None, None
 
 
 def fused_data_losses(coarse, gt_rgb, mask, bg_value=1.0):
-    """Same three terms as data_losses(), computed by the fused HIP loss tail (no host synchronisation)."""
+    """Same three terms as data_losses(), computed by the fused HIP loss tail (no host synchronisation); `total_loss` is
+    their sum in the reference's order ((bg + head) + nonhead), formed by the kernel."""
     t = _FusedDataLoss.apply(coarse["merge_img"], coarse["bg_img"], gt_rgb, mask, bg_value)
-    return {"bg_loss": t[0], "head_loss": t[1], "nonhead_loss": t[2]}
+    return {"bg_loss": t[0], "head_loss": t[1], "nonhead_loss": t[2], "total_loss": t[3]}
 
 
 class HeadNeRFLossUtils(object):
@@ -111,10 +123,9 @@ class HeadNeRFLossUtils(object):
         out in the reference, so the first two and the last two arguments are accepted and unused, as there)."""
         t = fused_data_losses(pred_dict["coarse_dict"], gt_rgb, mask_tensor, self.bg_value)
         loss_dict = {"bg_loss": t["bg_loss"], "head_loss": t["head_loss"], "nonhaed_loss": t["nonhead_loss"]}
-        total_loss = 0.0
-        for k in loss_dict:
-            total_loss += loss_dict[k]
-        loss_dict["total_loss"] = total_loss
+        # the reference adds the entries up in dict order (0.0 + bg + head + nonhead, :228-231); the kernel forms the same
+        # sum in the same order, so the autograd graph has one node instead of three additions
+        loss_dict["total_loss"] = t["total_loss"]
         return loss_dict
 
 
@@ -131,7 +142,7 @@ def train_step(net, optimizer, inputs, gt_rgb, mask, t_rand=None, extra_optimize
                shape_code=inputs["shape_code"], appea_code=inputs["appea_code"], batch_Rmats=inputs["batch_Rmats"],
                batch_Tvecs=inputs["batch_Tvecs"], batch_inv_inmats=inputs["batch_inv_inmats"], t_rand=t_rand)
     terms = (fused_data_losses if fused_loss else data_losses)(pred["coarse_dict"], gt_rgb, mask)
-    total = terms["bg_loss"] + terms["head_loss"] + terms["nonhead_loss"]
+    total = terms["total_loss"] if "total_loss" in terms else terms["bg_loss"] + terms["head_loss"] + terms["nonhead_loss"]
     for o in extra_optimizers:
         o.zero_grad()
     optimizer.zero_grad()

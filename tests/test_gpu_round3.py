@@ -192,39 +192,70 @@ def test_gradient_arena_holds_the_same_gradients_as_fresh_buffers(train_precisio
         torch.testing.assert_close(p.grad, gf[n], **tol, msg=lambda m, n=n: "step 2 %s: %s" % (n, m))
 
 
-def test_weight_gradient_atomics_scopes_agree():
-    """The fused weight-gradient kernel combines its slices in per-XCD partial buffers with atomics that stay in that XCD's L2
-    (train_x16.inc, dw_x16_body); N3DT_DW_ATOMICS=agent selects the formally race-free agent-scope form of the same thing.
-    Both must give the same gradients (up to fp32 summation order) at a size where every XCD holds several workgroups."""
+def test_bf16_and_fp32_training_converge_to_the_same_loss():
+    """convergence equivalence of the fused mixed-precision training path.  200 Adam steps (lr 1e-4, the
+    reference's optimizer, talker_trainer.py:722-723) at config 4's geometry (32 x 32 rays x 64 samples -> 256^2, B = 2) from the
+    same weights, data and stratified jitter, once with train_precision="fp32" (the exact path pinned to the reference's
+    autograd) and once with "bf16": the loss curves stay within 2 % of each other at steps 50 / 100 (measured: 0.01 %) and within
+    10 % at step 200 (measured: bf16 4 - 8 % lower, after a 160-fold fall of the loss; two fp32 runs differ by 0.3 - 4 % there) and the images the two
+    trained networks render (exact fp32 inference) agree within 5e-3 on average (99 % of the pixels within 2.5e-2)."""
     from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
     from n3dt.train import fused_data_losses, disk_mask
-    opt = BaseOptions({"featmap_size": 32, "featmap_nc": 256, "pred_img_size": 128, "num_sample_coarse": 64})
+    opt = BaseOptions({"featmap_size": 32, "featmap_nc": 256, "pred_img_size": 256, "num_sample_coarse": 64})
     sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
-    d = to_dev(syn.frame_inputs(opt, 2))
-    gt = torch.full((2, 3, 128, 128), 0.5, device=dev())
-    mask = disk_mask(2, 128).to(dev())
-    t_rand = syn.stratified_noise(2, 1024, 64, seed=3).to(dev())
+    B = 2
+    d = to_dev(syn.frame_inputs(opt, B))
+    mask = disk_mask(B, 256).to(dev())
+    # a target with structure (not a constant): a smooth colour ramp inside the head mask
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, 256), torch.linspace(0, 1, 256), indexing="ij")
+    gt = torch.stack([0.3 + 0.4 * xx, 0.6 - 0.3 * yy, 0.5 + 0.2 * xx * yy]).unsqueeze(0).repeat(B, 1, 1, 1).to(dev())
+    args = lambda: (d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],  # noqa: E731
+                    d["batch_Tvecs"], d["batch_inv_inmats"])
 
-    def grads(scope):
-        old = os.environ.pop("N3DT_DW_ATOMICS", None)
-        if scope:
-            os.environ["N3DT_DW_ATOMICS"] = scope
-        try:
-            net = HeadNeRFNet(opt, False, False, train_precision="bf16").to(dev())
-            net.load_state_dict(sd, strict=True)
-            out = net("train", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
-                      d["batch_Tvecs"], d["batch_inv_inmats"], t_rand=t_rand)
-            t = fused_data_losses(out["coarse_dict"], gt, mask)
-            (t["bg_loss"] + t["head_loss"] + t["nonhead_loss"]).backward()
-            torch.cuda.synchronize()
-            return {n: p.grad.clone() for n, p in net.named_parameters()}
-        finally:
-            os.environ.pop("N3DT_DW_ATOMICS", None)
-            if old is not None:
-                os.environ["N3DT_DW_ATOMICS"] = old
+    def run(train_precision):
+        net = HeadNeRFNet(opt, False, False, precision="fp32", train_precision=train_precision).to(dev())
+        net.load_state_dict(sd, strict=True)
+        optim = torch.optim.Adam(net.parameters(), lr=1e-4)
+        gen = torch.Generator(device=dev()).manual_seed(11)
+        curve = []
+        for step in range(200):
+            t_rand = torch.rand(B, 1024, 65, generator=gen, device=dev())
+            out = net("train", *args(), t_rand=t_rand)
+            loss = fused_data_losses(out["coarse_dict"], gt, mask)["total_loss"]
+            optim.zero_grad()
+            loss.backward()
+            optim.step()
+            curve.append(loss.detach())
+        curve = torch.stack(curve).cpu().numpy()
+        with torch.no_grad():
+            img = net("test", *args())["coarse_dict"]["merge_img"].clone()
+        return curve, img
 
-    a, b = grads(None), grads("agent")
-    for n in a:
-        scale = float(a[n].abs().max()) + 1e-20
-        err = float((a[n] - b[n]).abs().max()) / scale
-        assert err <= 2e-4, "%s: workgroup- vs agent-scope partials differ by %.2e of scale" % (n, err)
+    c32, i32 = run("fp32")
+    c32b, i32b = run("fp32")   # the exact path again: its fp32 atomics sum in a different order every run -- the noise floor
+    c16, i16 = run("bf16")
+    print("loss fp32:", c32[[0, 49, 99, 199]], " fp32 again:", c32b[[0, 49, 99, 199]], " bf16:", c16[[0, 49, 99, 199]])
+    assert c32[199] < 0.05 * c32[0], "the fp32 run did not train"
+    for k in (49, 99, 199):
+        # (mean of five steps around k: the stratified jitter makes single steps noisy.)  After a 150-fold fall of the loss two
+        # runs of the SAME fp32 path differ by a few per cent at step 200 (summation order alone); the bf16 run must sit within
+        # 2 % of the fp32 runs plus that spread
+        a, a2, b = c32[k - 4:k + 1].mean(), c32b[k - 4:k + 1].mean(), c16[k - 4:k + 1].mean()
+        ref, spread = 0.5 * (a + a2), abs(a - a2)
+        print("step %d: fp32 %.6f / %.6f, bf16 %.6f (%.2f %% off their mean; fp32 spread %.2f %%)" % (k + 1, a, a2, b, 100 * abs(b - ref) / ref, 100 * spread / ref))
+        # measured (three boxes): steps 50 / 100 agree to 0.01 %; at step 200, where the loss has fallen 160-fold, the bf16 run
+        # is 4 - 8 % BELOW the fp32 runs (0.00448 - 0.00501 against 0.00475 - 0.00505)
+        tol = 0.02 if k < 150 else 0.10
+        assert abs(b - ref) <= tol * ref + 2.0 * spread, "step %d: fp32 %.6f / %.6f, bf16 %.6f" % (k + 1, a, a2, b)
+    def stats(a, b):
+        diff = (a - b).abs().flatten()
+        q = torch.quantile(diff[::7].float(), torch.tensor([0.5, 0.99], device=diff.device)).tolist()
+        return float(diff.mean()), q[0], q[1], float(diff.max())
+
+    s16, s32 = stats(i32, i16), stats(i32, i32b)
+    print("final images, bf16 vs fp32 : mean |diff| %.2e, median %.2e, p99 %.2e, max %.2e" % s16)
+    print("final images, fp32 vs fp32 : mean |diff| %.2e, median %.2e, p99 %.2e, max %.2e" % s32)
+    # Two 200-step trajectories are not pixel-identical even in the SAME arithmetic (second line: fp32 atomics sum in a different
+    # order each run): part of the image is still moving fast at step 200.  The bf16 run must stay within 5e-3 (mean) / 2.5e-2
+    # (99 % of the pixels) of the fp32 run beyond three times that floor.
+    assert s16[0] <= 5e-3 + 3.0 * s32[0] and s16[2] <= 2.5e-2 + 3.0 * s32[2]

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), "libn3dt.so does not export %s" % name
-    assert L.n3dt_abi_version() == 3
+    assert L.n3dt_abi_version() == 4
 
 
 def test_geometry_validation_without_a_gpu():
