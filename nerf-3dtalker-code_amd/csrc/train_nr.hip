@@ -60,8 +60,18 @@ static NrWs nr_ws_layout(const N3dtGeom* g, int nb) {
     return w;
 }
 
-extern "C" size_t n3dt_nr_train_saved_floats(const N3dtGeom* g, int nb) { return nr_saved_layout(g, nb).total; }
-extern "C" size_t n3dt_nr_train_ws_floats(const N3dtGeom* g, int nb) { return nr_ws_layout(g, nb).total; }
+// (the sizes cover both the layered layouts above and the fused mixed-precision path's, nr_train16.h: the size queries of the
+// C ABI do not take the precision)
+extern "C" size_t n3dt_nr_train16_saved_bytes(const N3dtGeom* g, int nb);
+extern "C" size_t n3dt_nr_train16_ws_bytes(const N3dtGeom* g, int nb);
+extern "C" size_t n3dt_nr_train_saved_floats(const N3dtGeom* g, int nb) {
+    const size_t a = nr_saved_layout(g, nb).total, b = (n3dt_nr_train16_saved_bytes(g, nb) + 3) / 4;
+    return a > b ? a : b;
+}
+extern "C" size_t n3dt_nr_train_ws_floats(const N3dtGeom* g, int nb) {
+    const size_t a = nr_ws_layout(g, nb).total, b = (n3dt_nr_train16_ws_bytes(g, nb) + 3) / 4;
+    return a > b ? a : b;
+}
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
@@ -564,9 +574,42 @@ static constexpr int is16() { return sizeof(T) == 2 ? 1 : 0; }
 // small enough (1 KiB) that the load pipe is nowhere near its limit.  fp32 atomics combine the pixel ranges.
 typedef __bf16 nrt_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short nrt_u16x8 __attribute__((ext_vector_type(8)));
-template <int TO, int TI, class TX>
-__global__ __launch_bounds__(256) void nrt_dw16_kernel(int co, int ci, long K, const nrt_bf16* __restrict__ dY, const TX* __restrict__ X,
-                                                       float* __restrict__ out, long ldo, long chunk, float* __restrict__ db) {
+// The X operand is read through a loader XL (value of element [plane][pixel][channel] as float): a row-major matrix (DwRows),
+// or the pixel-shuffled map ps = y + x.repeat rebuilt on the fly from the saved sub-pixel planes and the block input (DwPs).
+// PM (plane mode):
+//   0  one product; the four waves of a workgroup split its pixel chunk and hold partial sums of the SAME output tiles.
+//   1  dY (and X) come as four sub-pixel planes of K pixels each that all add into the SAME output (d Wf): wave w walks the whole
+//      chunk of plane w -- the plane is wave-uniform, and the four waves read the same rows of the shared operand (x) through L1.
+// blockIdx.z = p (PM 0) walks independent products of one shape (d W2: plane q of d_tv against t1 gives rows 4c + q): dY, out, db
+// advance by dy_plane / out_plane / db_plane per plane, db entries are db_stride apart.  (Measured and dropped: "wave = plane,
+// own outputs" for d W2 -- t1 fetched once for the four planes, but four times the atomics per workgroup: 109 / 69 / 67 us
+// became 158 / 115 / 95.  And PM 1 on the smallest block (32 x 64 outputs): 73 -> 150 us, so that one keeps PM 0.)
+template <class TX>
+struct DwRows {
+    const TX* X;
+    int ci;
+    __device__ __forceinline__ float operator()(const int, const long pix, const int ch) const { return nrt_ld(X + pix * ci + ch); }
+};
+template <class TX>
+struct DwPs {  // value = y_q[m][ch] + x[m][(4 ch + q) % C]
+    const nrt_bf16* y;
+    const TX* x;
+    long M;
+    int C;
+    __device__ __forceinline__ float operator()(const int plane, const long pix, const int ch) const {
+        // plane >= 0: wave-uniform sub-pixel, pix = m;  plane < 0 (PM 0): pix is the plane-major row q M + m
+        const int q = plane >= 0 ? plane : (int)((pix >= M) + (pix >= 2 * M) + (pix >= 3 * M));
+        const long m = plane >= 0 ? pix : pix - (long)q * M;
+        return nrt_ld(y + ((long)q * M + m) * C + ch) + nrt_ld(x + m * C + ((4 * ch + q) & (C - 1)));
+    }
+};
+struct DwPlanes {
+    long dy_plane, out_plane;
+    int db_plane, db_stride;
+};
+template <int TO, int TI, class XL, int PM = 0>
+__global__ __launch_bounds__(256) void nrt_dw16_kernel(int co, int ci, long K, const nrt_bf16* __restrict__ dY, const XL X,
+                                                       float* __restrict__ out, long ldo, long chunk, float* __restrict__ db, const DwPlanes pl) {
     // db (nullable): the bias gradient db[c] += sum over pixels of dY[pix][c] rides along on the workgroups of the first input
     // tile group -- the column sums of the fragments they load anyway (a separate column-sum pass re-read dY: 9 launches, 0.26 ms
     // of the 8 ms training step)
@@ -574,10 +617,17 @@ __global__ __launch_bounds__(256) void nrt_dw16_kernel(int co, int ci, long K, c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int tiles_i = (ci / 32 + TI - 1) / TI;
     const int o0 = (blockIdx.y / tiles_i) * TO * 32, i0 = (blockIdx.y % tiles_i) * TI * 32;
-    // the workgroup's pixel chunk, split evenly over its 4 waves in multiples of 16 pixels
+    // the workgroup's pixel chunk: split evenly over its 4 waves in multiples of 16 pixels (PM 0), or walked whole by every
+    // wave on its own plane (PM 1, 2)
     const long c0 = (long)blockIdx.x * chunk, c1 = min(K, c0 + chunk);
-    const long per = ((c1 - c0 + 3) / 4 + 15) / 16 * 16;
-    const long p0 = c0 + wave * per, p1 = min(c1, p0 + per);
+    const long per = PM == 0 ? ((c1 - c0 + 3) / 4 + 15) / 16 * 16 : (c1 - c0);
+    const long p0 = PM == 0 ? c0 + wave * per : c0, p1 = min(c1, p0 + per);
+    if (PM != 0) dY += (long)wave * pl.dy_plane;
+    if (PM == 0) {
+        dY += (long)blockIdx.z * pl.dy_plane;
+        out += (long)blockIdx.z * pl.out_plane;
+        if (db) db += (long)blockIdx.z * pl.db_plane;
+    }
     f32x16 acc[TO][TI];
     float rs[TO];
 #pragma unroll
@@ -614,7 +664,7 @@ __global__ __launch_bounds__(256) void nrt_dw16_kernel(int co, int ci, long K, c
             const int ch = min(i0 + 32 * b + r, ci - 1);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float v = (!guard || pb + j < p1) ? nrt_ld(X + (pb + j) * ci + ch) : 0.0f;
+                const float v = (!guard || pb + j < p1) ? X(PM == 0 ? -1 : wave, pb + j, ch) : 0.0f;
                 u[j] = __builtin_bit_cast(unsigned short, (__bf16)v);
             }
             fb[b] = __builtin_bit_cast(nrt_bf16x8, u);
@@ -636,7 +686,7 @@ __global__ __launch_bounds__(256) void nrt_dw16_kernel(int co, int ci, long K, c
         __syncthreads();
         for (int i = threadIdx.x; i < TO * 32; i += 256) {
             const int ch = o0 + i;
-            if (ch < co) atomicAdd(db + ch, (rs_red[0][i] + rs_red[1][i]) + (rs_red[2][i] + rs_red[3][i]));
+            if (ch < co) atomicAdd(db + (long)ch * pl.db_stride, (rs_red[0][i] + rs_red[1][i]) + (rs_red[2][i] + rs_red[3][i]));
         }
     }
     // The four waves of the workgroup hold four partial sums of the SAME output tiles (disjoint pixel ranges).  They are
@@ -669,24 +719,31 @@ __global__ __launch_bounds__(256) void nrt_dw16_kernel(int co, int ci, long K, c
             }
         }
 }
-template <class TX>
-static void launch_dw16(int co, int ci, long K, const nrt_bf16* dY, const TX* X, float* out, long ldo, float* db, hipStream_t s) {
-    // 64 x 128 outputs per wave (fewer when the layer is smaller); about 512 workgroups of 4 waves, >= 1024 pixels each
+template <class XL, int PM = 0>
+static void launch_dw16_x(int co, int ci, long K, const nrt_bf16* dY, const XL X, float* out, long ldo, float* db, hipStream_t s, int planes = 1,
+                          const DwPlanes pl = DwPlanes{0, 0, 0, 1}) {
+    // 64 x 128 outputs per wave (fewer when the layer is smaller); about 512 workgroups of 4 waves.  PM 0: >= 1024 pixels per
+    // workgroup (256 per wave); PM 1: every wave walks the whole chunk of its plane, >= 256 pixels
     const int groups = ((co / 32 + 1) / 2) * ((ci / 32 + 3) / 4);
-    long slices = 512 / groups;
-    if (slices > K / 1024) slices = K / 1024;
+    const long min_chunk = PM == 0 ? 1024 : 256;
+    long slices = 512 / ((long)groups * planes);
+    if (slices > K / min_chunk) slices = K / min_chunk;
     if (slices < 1) slices = 1;
     const long chunk = ((K + slices - 1) / slices + 63) / 64 * 64;
-    dim3 grid((unsigned)((K + chunk - 1) / chunk), groups);
+    dim3 grid((unsigned)((K + chunk - 1) / chunk), groups, planes);
     if (co <= 32 && ci <= 64) {
-        hipLaunchKernelGGL((nrt_dw16_kernel<1, 2, TX>), dim3(grid.x, 1), dim3(256), (size_t)4 * 2 * 16 * 64 * sizeof(float), s, co, ci, K, dY, X, out,
-                           ldo, chunk, db);
+        hipLaunchKernelGGL((nrt_dw16_kernel<1, 2, XL, PM>), dim3(grid.x, 1, planes), dim3(256), (size_t)4 * 2 * 16 * 64 * sizeof(float), s, co, ci, K,
+                           dY, X, out, ldo, chunk, db, pl);
     } else {
-        auto kern = nrt_dw16_kernel<2, 4, TX>;
+        auto kern = nrt_dw16_kernel<2, 4, XL, PM>;
         const size_t lds = (size_t)4 * 8 * 16 * 64 * sizeof(float);  // 128 KiB
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, co, ci, K, dY, X, out, ldo, chunk, db);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, co, ci, K, dY, X, out, ldo, chunk, db, pl);
     }
+}
+template <class TX>
+static void launch_dw16(int co, int ci, long K, const nrt_bf16* dY, const TX* X, float* out, long ldo, float* db, hipStream_t s) {
+    launch_dw16_x<DwRows<TX>, 0>(co, ci, K, dY, DwRows<TX>{X, ci}, out, ldo, db, s);
 }
 
 // to fp32 at the boundary (d_featmap is fp32 in both modes)
@@ -773,9 +830,269 @@ static void nr_train_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, c
     (void)hipMemcpyAsync(img, img_saved, sizeof(float) * nb * 3 * P * P, hipMemcpyDeviceToDevice, s);
 }
 
+// =====================================================================================================================
+// Fused mixed-precision training path (bf16 maps), backward.  The forward (neural_render.hip: n3dt_launch_nr_train16_fwd)
+// is the inference sequence with a save epilogue; what it keeps is listed in nr_train16.h.  Per block, from the last:
+//   d_pre  = (d net from the next block + feat_2_rgb^T d rgb) * lrelu'(net)            nr16_dpre_kernel          raster [4M][CO]
+//   d W_rgb, d b_rgb                                                                   (the exact path's reductions)
+//   d hid  = Blur^T d_pre, written as the four sub-pixel planes                        nr16_blur_adj_q_kernel    [4][M][CO]
+//   d Wf  += d hid^T ps,  ps = y + x.repeat rebuilt by the loader; d bf = column sums  nrt_dw16_kernel<DwPs>
+//   d tv   = (d hid . Wf) * lrelu'(y)     -- the un-shuffle is the plane layout        gemm_h (gate epilogue)    [4][M][C]
+//   d W2  += d tv_q^T t1 per plane (row 4c + q), d b2                                  nrt_dw16_kernel, grid.z = q
+//   d t1   = (sum_q d tv_q . W2_q) * lrelu'(t1)                                        gemm_h, A = 4 regions     [M][2C]
+//   d W1  += d t1^T x, d b1                                                            nrt_dw16_kernel
+//   d x    = d t1 . W1 + sum_q d hid_q . R_q   (the residual's path, as in the forward) gemm_h, A = 5 regions    [M][C]
+//   d rgb at the block's input resolution: Blur^T, bilinear^T                          (planar kernels)
+// Against the layered version this drops, per block, the blur adjoint at full channel width (it runs on CO = C/2 channels
+// here, the Blur being commuted behind feat_layers as in the forward), the un-shuffle pass, the separate gate pass and the
+// three weight transposes (one pack launch per block instead).
+#include "nr_train16.h"
+extern "C" void n3dt_launch_nr_train16_fwd(const N3dtGeom*, int, const N3dtRenderParams*, const float*, float*, unsigned char*, unsigned char*,
+                                           hipStream_t);
+extern "C" void n3dt_launch_gemm_regions_bf16(int, int, int, int, const void* const*, const int*, const int*, const float*, const void*, void*,
+                                              hipStream_t);
+
+// the three transposed / permuted fp32 matrices of one block (nr_train16.h: Nr16Wt)
+__global__ void nr16_pack_wt_kernel(int C, int CO, const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ Wf,
+                                    float* __restrict__ out) {
+    const Nr16Wt L = nr16_wt_layout(C, CO);
+    const size_t n_g3 = (size_t)C * (2 * C + 4 * CO), total = L.g3 + n_g3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v;
+        if (i < L.g2) {  // g1: Wt[c][o] = Wf[o][c]
+            const int c = (int)(i / CO), o = (int)(i % CO);
+            v = Wf[(size_t)o * C + c];
+        } else if (i < L.g3) {  // g2: Wt[n][q C + c] = W2[4c + q][n]
+            const size_t j = i - L.g2;
+            const int n = (int)(j / (4 * C)), kk = (int)(j % (4 * C)), q = kk / C, c = kk % C;
+            v = W2[(size_t)(4 * c + q) * (2 * C) + n];
+        } else {  // g3: Wt[k][j] = W1[j][k] | R_q[o][k]
+            const size_t j = i - L.g3;
+            const int KK = 2 * C + 4 * CO, k = (int)(j / KK), kk = (int)(j % KK);
+            if (kk < 2 * C) {
+                v = W1[(size_t)kk * C + k];
+            } else {
+                const int r = kk - 2 * C, q = r / CO, o = r % CO;
+                v = 0.0f;
+                if ((k & 3) == q) {
+                    const float* wr = Wf + (size_t)o * C;
+                    const int c0 = (k - q) >> 2;
+                    v = (wr[c0] + wr[c0 + C / 4]) + (wr[c0 + C / 2] + wr[c0 + 3 * (C / 4)]);  // the forward's summation order
+                }
+            }
+        }
+        out[i] = v;
+    }
+}
+
+// d_pre[pix][k] = (d_in[pix][k] + sum_c d_rgb[img][c][p] Wrgb[c][k]) * lrelu'(net[pix][k]);  thread = pixel x 8 channels
+__global__ __launch_bounds__(256) void nr16_dpre_kernel(int nb, int HW, int K, const float* __restrict__ d_rgb, const float* __restrict__ Wt,
+                                                        const nrt_bf16* __restrict__ net, const nrt_bf16* __restrict__ d_in,
+                                                        nrt_bf16* __restrict__ d_pre) {
+    extern __shared__ float wl[];
+    for (int i = threadIdx.x; i < 3 * K; i += blockDim.x) wl[i] = Wt[i];
+    __syncthreads();
+    const int k8 = K / 8, k8s = 31 - __builtin_clz(k8);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nb * HW * k8) return;
+    const int kq = (int)(i & (k8 - 1));
+    const size_t pix = i >> k8s, img = pix / HW, p = pix % HW, o = img * 3 * (size_t)HW + p;
+    const float d0 = d_rgb[o], d1 = d_rgb[o + HW], d2 = d_rgb[o + 2 * (size_t)HW];
+    const nrt_u16x8 g = *reinterpret_cast<const nrt_u16x8*>(net + pix * K + 8 * kq);
+    nrt_u16x8 din = (nrt_u16x8)(0);
+    if (d_in) din = *reinterpret_cast<const nrt_u16x8*>(d_in + pix * K + 8 * kq);
+    nrt_u16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = d0 * wl[8 * kq + j] + d1 * wl[K + 8 * kq + j] + d2 * wl[2 * K + 8 * kq + j];
+        v += __builtin_bit_cast(float, (unsigned)din[j] << 16);
+        const float y = __builtin_bit_cast(float, (unsigned)g[j] << 16);
+        v = y > 0.0f ? v : 0.2f * v;
+        out[j] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    }
+    *reinterpret_cast<nrt_u16x8*>(d_pre + pix * K + 8 * kq) = out;
+}
+
+// Adjoint of the reflect-border blur, raster [img][2H][2W][K] -> four sub-pixel planes [q][nb*H*W][K] (q = 2 di + dj is output
+// pixel (2h + di, 2w + dj) of input pixel (h, w)).  One thread = one input pixel x 8 channels: the four 3 x 3 adjoint stencils
+// share a 4 x 4 neighbourhood (16 loads of 16 bytes), weights from blur_adj_w3 (clamped taps carry weight 0).
+__global__ __launch_bounds__(256) void nr16_blur_adj_q_kernel(int nb, int H, int W, int K, const nrt_bf16* __restrict__ d_pre,
+                                                              nrt_bf16* __restrict__ d_hid) {
+    const int k8 = K / 8, k8s = 31 - __builtin_clz(k8);
+    const size_t Mq = (size_t)nb * H * W;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Mq * k8) return;
+    const int kq = (int)(i & (k8 - 1));
+    const size_t pix = i >> k8s;
+    const int w = (int)(pix % W), h = (int)((pix / W) % H), img = (int)(pix / ((size_t)W * H));
+    const int H2 = 2 * H, W2 = 2 * W;
+    float wr[2][3], wc[2][3];
+    blur_adj_w3(2 * h, H2, wr[0]);
+    blur_adj_w3(2 * h + 1, H2, wr[1]);
+    blur_adj_w3(2 * w, W2, wc[0]);
+    blur_adj_w3(2 * w + 1, W2, wc[1]);
+    float acc[2][2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[a][b][j] = 0.0f;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {  // raster rows 2h-1 .. 2h+2
+        const int r = min(max(2 * h - 1 + rr, 0), H2 - 1);
+        float t4[4][8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = min(max(2 * w - 1 + t, 0), W2 - 1);
+            const nrt_u16x8 v = *reinterpret_cast<const nrt_u16x8*>(d_pre + (((size_t)img * H2 + r) * W2 + c) * K + 8 * kq);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t4[t][j] = __builtin_bit_cast(float, (unsigned)v[j] << 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // horizontal three taps for output columns 2w (taps t = 0..2) and 2w+1 (t = 1..3)
+            const float h0 = wc[0][0] * t4[0][j] + wc[0][1] * t4[1][j] + wc[0][2] * t4[2][j];
+            const float h1 = wc[1][0] * t4[1][j] + wc[1][1] * t4[2][j] + wc[1][2] * t4[3][j];
+            if (rr < 3) {  // row 2h reads raster rows rr = 0..2
+                acc[0][0][j] = fmaf(wr[0][rr < 3 ? rr : 0], h0, acc[0][0][j]);
+                acc[0][1][j] = fmaf(wr[0][rr < 3 ? rr : 0], h1, acc[0][1][j]);
+            }
+            if (rr > 0) {  // row 2h+1 reads raster rows rr = 1..3
+                acc[1][0][j] = fmaf(wr[1][rr > 0 ? rr - 1 : 0], h0, acc[1][0][j]);
+                acc[1][1][j] = fmaf(wr[1][rr > 0 ? rr - 1 : 0], h1, acc[1][1][j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+            nrt_u16x8 out;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[j] = __builtin_bit_cast(unsigned short, (__bf16)acc[di][dj][j]);
+            *reinterpret_cast<nrt_u16x8*>(d_hid + ((size_t)(2 * di + dj) * Mq + pix) * K + 8 * kq) = out;
+        }
+}
+
+// d_featmap[pix][k] = d_x[pix][k] (16-bit) + sum_c d_rgb0[img][c][p] Wrgb0[c][k]   (the stage-0 rgb branch), fp32 out
+__global__ __launch_bounds__(256) void nr16_final_kernel(int nb, int HW, int K, const float* __restrict__ d_rgb, const float* __restrict__ Wt,
+                                                         const nrt_bf16* __restrict__ dx, float* __restrict__ d_feat) {
+    extern __shared__ float wl[];
+    for (int i = threadIdx.x; i < 3 * K; i += blockDim.x) wl[i] = Wt[i];
+    __syncthreads();
+    const int k4 = K / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nb * HW * k4) return;
+    const int kq = (int)(i % k4);
+    const size_t pix = i / k4, img = pix / HW, p = pix % HW, o = img * 3 * (size_t)HW + p;
+    const float d0 = d_rgb[o], d1 = d_rgb[o + HW], d2 = d_rgb[o + 2 * (size_t)HW];
+    const f32x4 x = nrt_ld4(dx + pix * K + 4 * kq);
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = x[j] + (d0 * wl[4 * kq + j] + d1 * wl[K + 4 * kq + j] + d2 * wl[2 * K + 4 * kq + j]);
+    *reinterpret_cast<f32x4*>(d_feat + pix * K + 4 * kq) = v;
+}
+
+static void nr_bwd16(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N3dtRenderGrads* gp, const float* featmap, const float* d_img,
+                     const unsigned char* saved, float* d_featmap, unsigned char* ws, hipStream_t s) {
+    const Nr16Saved sv = nr16_saved_layout(g, nb);
+    const Nr16Ws wl = nr16_ws_layout(g, nb);
+    const int C0 = g->feat_nc, nblk = g->n_blocks;
+    const size_t P = (size_t)g->featmap_size << nblk;
+    nrt_bf16* dpre = reinterpret_cast<nrt_bf16*>(ws + wl.dpre);
+    nrt_bf16* dhid = reinterpret_cast<nrt_bf16*>(ws + wl.dhid);
+    nrt_bf16* dtv = reinterpret_cast<nrt_bf16*>(ws + wl.dtv);
+    nrt_bf16* dt1 = reinterpret_cast<nrt_bf16*>(ws + wl.dt1);
+    nrt_bf16* dxa = reinterpret_cast<nrt_bf16*>(ws + wl.dxa);
+    nrt_bf16* dxb = reinterpret_cast<nrt_bf16*>(ws + wl.dxb);
+    float* drgb = reinterpret_cast<float*>(ws + wl.drgb);
+    float* dtmp = reinterpret_cast<float*>(ws + wl.dtmp);
+    // the transposed weights of every block (weights moved since the last step: packed per call)
+    for (int i = 0; i < nblk; ++i) {
+        const int ci = nr16_ch(C0, i), co = nr16_ch(C0, i + 1);
+        hipLaunchKernelGGL(nr16_pack_wt_kernel, dim3(256), dim3(256), 0, s, ci, co, p->psu1_w[i], p->psu2_w[i], p->feat_w[i],
+                           reinterpret_cast<float*>(ws + wl.wt[i]));
+    }
+    int h = (int)P;
+    hipLaunchKernelGGL(nrt_sigmoid_bwd_kernel, GRID1((size_t)nb * 3 * P * P), 0, s, (size_t)nb * 3 * P * P,
+                       reinterpret_cast<const float*>(saved + sv.img), d_img, drgb);
+    const nrt_bf16* dnet_in = nullptr;  // d net_i from block i + 1 (its d x), raster [4M][co]
+    nrt_bf16* dx_out = dxa;
+    for (int i = nblk - 1; i >= 0; --i) {
+        const int ci = nr16_ch(C0, i), co = nr16_ch(C0, i + 1);
+        const int hin = h / 2, M = nb * hin * hin, M4 = nb * h * h, HW = h * h;
+        const nrt_bf16* net = reinterpret_cast<const nrt_bf16*>(saved + sv.net[i]);
+        const nrt_bf16* y = reinterpret_cast<const nrt_bf16*>(saved + sv.y[i]);
+        const nrt_bf16* t1 = reinterpret_cast<const nrt_bf16*>(saved + sv.t1[i]);
+        const nrt_bf16* x16 = i > 0 ? reinterpret_cast<const nrt_bf16*>(saved + sv.net[i - 1]) : nullptr;
+        const float* wt = reinterpret_cast<const float*>(ws + wl.wt[i]);
+        const Nr16Wt L = nr16_wt_layout(ci, co);
+        // feat_2_rgb[i + 1]: parameter gradients; d_pre
+        launch_to_rgb_wgrad<nrt_bf16>(nb, HW, co, drgb, net, gp->to_rgb_w[i + 1], s);
+        hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[i + 1]);
+        hipLaunchKernelGGL(nr16_dpre_kernel, GRID1((size_t)M4 * (co / 8)), 3 * co * sizeof(float), s, nb, HW, co, (const float*)drgb,
+                           p->to_rgb_w[i + 1], net, dnet_in, dpre);
+        hipLaunchKernelGGL(nr16_blur_adj_q_kernel, GRID1((size_t)M * (co / 8)), 0, s, nb, hin, hin, co, (const nrt_bf16*)dpre, dhid);
+        // feat_layers: d Wf += d hid^T ps (+ d bf), over all four planes' pixels
+        if (i == 0)
+            launch_dw16_x<DwPs<float>, 1>(co, ci, (long)M, dhid, DwPs<float>{y, featmap, (long)M, ci}, gp->feat_w[i], ci, gp->feat_b[i], s, 1,
+                                          DwPlanes{(long)M * co, 0, 0, 1});
+        else if (co > 32)
+            launch_dw16_x<DwPs<nrt_bf16>, 1>(co, ci, (long)M, dhid, DwPs<nrt_bf16>{y, x16, (long)M, ci}, gp->feat_w[i], ci, gp->feat_b[i], s, 1,
+                                             DwPlanes{(long)M * co, 0, 0, 1});
+        else  // the 32 x 64 block: the four planes as 4 M rows, waves split the pixels
+            launch_dw16_x<DwPs<nrt_bf16>, 0>(co, ci, (long)M4, dhid, DwPs<nrt_bf16>{y, x16, (long)M, ci}, gp->feat_w[i], ci, gp->feat_b[i], s);
+        {   // d tv (planes) = (d hid . Wf) * lrelu'(y)
+            const void* base[1] = {dhid};
+            const int width[1] = {co}, ld[1] = {co};
+            n3dt_launch_gemm_regions_bf16(M4, ci, co, 1, base, width, ld, wt + L.g1, y, dtv, s);
+        }
+        // layer_2: d W2[4c + q][:] += d tv_q^T t1 (+ d b2[4c + q]), one product per plane in one launch
+        launch_dw16_x<DwRows<nrt_bf16>, 0>(ci, 2 * ci, (long)M, dtv, DwRows<nrt_bf16>{t1, 2 * ci}, gp->psu2_w[i], (long)4 * 2 * ci, gp->psu2_b[i], s, 4,
+                                           DwPlanes{(long)M * ci, (long)2 * ci, 1, 4});
+        {   // d t1 = (sum_q d tv_q . W2_q) * lrelu'(t1)
+            const void* base[4] = {dtv, dtv + (size_t)M * ci, dtv + (size_t)2 * M * ci, dtv + (size_t)3 * M * ci};
+            const int width[4] = {ci, ci, ci, ci}, ld[4] = {ci, ci, ci, ci};
+            n3dt_launch_gemm_regions_bf16(M, 2 * ci, 4 * ci, 4, base, width, ld, wt + L.g2, t1, dt1, s);
+        }
+        // layer_1: d W1 += d t1^T x (+ d b1)
+        if (i == 0) launch_dw16<float>(2 * ci, ci, (long)M, dt1, featmap, gp->psu1_w[i], ci, gp->psu1_b[i], s);
+        else launch_dw16<nrt_bf16>(2 * ci, ci, (long)M, dt1, x16, gp->psu1_w[i], ci, gp->psu1_b[i], s);
+        {   // d x = d t1 . W1 + sum_q d hid_q . R_q
+            const void* base[5] = {dt1, dhid, dhid + (size_t)M * co, dhid + (size_t)2 * M * co, dhid + (size_t)3 * M * co};
+            const int width[5] = {2 * ci, co, co, co, co}, ld[5] = {2 * ci, co, co, co, co};
+            n3dt_launch_gemm_regions_bf16(M, ci, 2 * ci + 4 * co, 5, base, width, ld, wt + L.g3, nullptr, dx_out, s);
+        }
+        // rgb pyramid: the running rgb at this block's output came from rgb_upsample of the sum at its input resolution
+        h = hin;
+        hipLaunchKernelGGL(nrt_blur_adj_planar_kernel, GRID1((size_t)nb * 3 * 4 * h * h), 0, s, nb * 3, 2 * h, 2 * h, drgb, dtmp);
+        hipLaunchKernelGGL(nrt_bilinear_adj_kernel, GRID1((size_t)nb * 3 * h * h), 0, s, nb * 3, h, h, dtmp, drgb);
+        dnet_in = dx_out;
+        dx_out = dx_out == dxa ? dxb : dxa;
+    }
+    // stage-0 rgb: feat_2_rgb_list[0](featmap); d featmap = d x_0 + its branch
+    {
+        const int fs = g->featmap_size, HW = fs * fs;
+        launch_to_rgb_wgrad<float>(nb, HW, C0, drgb, featmap, gp->to_rgb_w[0], s);
+        hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[0]);
+        hipLaunchKernelGGL(nr16_final_kernel, GRID1((size_t)nb * HW * (C0 / 4)), 3 * C0 * sizeof(float), s, nb, HW, C0, (const float*)drgb,
+                           p->to_rgb_w[0], dnet_in, d_featmap);
+    }
+}
+
+static bool nr16_enabled(const N3dtGeom* g) {
+    const char* e = getenv("N3DT_NR_TRAIN_FUSED");  // 0: the layered bf16 path (A/B)
+    return (!e || atoi(e) != 0) && nr16_supported(g);
+}
+extern "C" size_t n3dt_nr_train16_saved_bytes(const N3dtGeom* g, int nb) { return nr16_saved_layout(g, nb).total; }
+extern "C" size_t n3dt_nr_train16_ws_bytes(const N3dtGeom* g, int nb) { return nr16_ws_layout(g, nb).total; }
+
 extern "C" void n3dt_launch_nr_train_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const float* featmap, float* img,
                                          float* saved, float* ws, int bf16, hipStream_t s) {
-    if (bf16) nr_train_fwd<nrt_bf16>(g, nb, p, featmap, img, saved, ws, s);
+    if (bf16 && nr16_enabled(g))
+        n3dt_launch_nr_train16_fwd(g, nb, p, featmap, img, reinterpret_cast<unsigned char*>(saved), reinterpret_cast<unsigned char*>(ws), s);
+    else if (bf16) nr_train_fwd<nrt_bf16>(g, nb, p, featmap, img, saved, ws, s);
     else nr_train_fwd<float>(g, nb, p, featmap, img, saved, ws, s);
 }
 
@@ -860,6 +1177,8 @@ static void nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N
 extern "C" void n3dt_launch_nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N3dtRenderGrads* gp,
                                    const float* featmap, const float* d_img, const float* saved, float* d_featmap, float* ws,
                                    int bf16, hipStream_t s) {
-    if (bf16) nr_bwd<nrt_bf16>(g, nb, p, gp, featmap, d_img, saved, d_featmap, ws, s);
+    if (bf16 && nr16_enabled(g))
+        nr_bwd16(g, nb, p, gp, featmap, d_img, reinterpret_cast<const unsigned char*>(saved), d_featmap, reinterpret_cast<unsigned char*>(ws), s);
+    else if (bf16) nr_bwd<nrt_bf16>(g, nb, p, gp, featmap, d_img, saved, d_featmap, ws, s);
     else nr_bwd<float>(g, nb, p, gp, featmap, d_img, saved, d_featmap, ws, s);
 }
