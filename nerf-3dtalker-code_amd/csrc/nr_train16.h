@@ -65,6 +65,7 @@ struct Nr16Ws {
     // backward: d_pre (raster) / d_hid (planes) [4M][CO], d_tv planes [4][M][C], d_t1 [M][2C], d_x ping-pong [M][C] (16-bit),
     // planar fp32 d_rgb ping-pong, transposed weights of every block
     size_t dpre, dhid, dtv, dt1, dxa, dxb, drgb, dtmp, wt[N3DT_MAX_BLOCKS];
+    size_t dwpart;  // per-XCD partial sums of the layer_2 / layer_1 weight gradients of every block (dw_rowmajor.h)
     size_t total;
 };
 size_t nrf_packed_bytes_for(int C, int CO);  // neural_render.hip (the fused block kernel's packed stream + bias table)
@@ -97,6 +98,11 @@ static inline Nr16Ws nr16_ws_layout(const N3dtGeom* g, int nb) {
     for (int i = 0; i < g->n_blocks; ++i) {
         w.wt[i] = o;
         o += nr16_al(nr16_wt_layout(nr16_ch(g->feat_nc, i), nr16_ch(g->feat_nc, i + 1)).floats * sizeof(float));
+    }
+    w.dwpart = o;
+    for (int i = 0; i < g->n_blocks; ++i) {
+        const size_t ci = nr16_ch(g->feat_nc, i);
+        o += nr16_al(sizeof(float) * 8 * (4 * ci) * (2 * ci)) + nr16_al(sizeof(float) * 8 * (2 * ci) * ci);
     }
     w.total = o;
     return w;

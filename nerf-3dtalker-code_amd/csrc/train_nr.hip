@@ -847,6 +847,7 @@ static void nr_train_fwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, c
 // here, the Blur being commuted behind feat_layers as in the forward), the un-shuffle pass, the separate gate pass and the
 // three weight transposes (one pack launch per block instead).
 #include "nr_train16.h"
+#include "dw_rowmajor.h"
 extern "C" void n3dt_launch_nr_train16_fwd(const N3dtGeom*, int, const N3dtRenderParams*, const float*, float*, unsigned char*, unsigned char*,
                                            hipStream_t);
 extern "C" void n3dt_launch_gemm_regions_bf16(int, int, int, int, const void* const*, const int*, const int*, const float*, const void*, void*,
@@ -1014,6 +1015,25 @@ static void nr_bwd16(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const
         hipLaunchKernelGGL(nr16_pack_wt_kernel, dim3(256), dim3(256), 0, s, ci, co, p->psu1_w[i], p->psu2_w[i], p->feat_w[i],
                            reinterpret_cast<float*>(ws + wl.wt[i]));
     }
+    // layer_2 / layer_1 weight gradients on the MLP's LDS-transposed kernel (row-major front end, dw_rowmajor.h) where the pixel
+    // count allows it: entries 2 i (d W2: the four planes of d_tv as one wide operand against t1) and 2 i + 1 (d W1: d_t1 against x)
+    N3dtDwRm dw[2 * N3DT_MAX_BLOCKS];
+    bool dw_ok[2 * N3DT_MAX_BLOCKS];
+    bool any_dw = false;
+    for (int i = 0; i < nblk; ++i) {
+        const int ci = nr16_ch(C0, i);
+        const long hh = (long)g->featmap_size << i, M = (long)nb * hh * hh;
+        dw[2 * i] = N3dtDwRm{dtv, ci, 4, (size_t)M * ci, saved + sv.t1[i], 2 * ci, M, 4 * ci, 2 * ci, gp->psu2_w[i], 2 * ci, ci, gp->psu2_b[i]};
+        dw[2 * i + 1] = N3dtDwRm{dt1, 2 * ci, 1, 0, i > 0 ? (const void*)(saved + sv.net[i - 1]) : nullptr, ci, M, 2 * ci, ci, gp->psu1_w[i], ci, 0,
+                                 gp->psu1_b[i]};
+        static const bool off_env = [] { const char* e = getenv("N3DT_NR_DW_LDS"); return e && atoi(e) == 0; }();
+        const bool off = off_env || 2 * nblk > N3DT_DW_RM_MAX;  // (the reduction launch carries at most N3DT_DW_RM_MAX products)
+        dw_ok[2 * i] = !off && n3dt_dw_rowmajor_ok(&dw[2 * i]);
+        dw_ok[2 * i + 1] = !off && i > 0 && n3dt_dw_rowmajor_ok(&dw[2 * i + 1]);  // (block 0's x is the fp32 feature map)
+        any_dw = any_dw || dw_ok[2 * i] || dw_ok[2 * i + 1];
+    }
+    float* dwpart = reinterpret_cast<float*>(ws + wl.dwpart);
+    if (any_dw) n3dt_launch_dw_rowmajor_zero(dw, 2 * nblk, dwpart, s);
     int h = (int)P;
     hipLaunchKernelGGL(nrt_sigmoid_bwd_kernel, GRID1((size_t)nb * 3 * P * P), 0, s, (size_t)nb * 3 * P * P,
                        reinterpret_cast<const float*>(saved + sv.img), d_img, drgb);
@@ -1049,15 +1069,18 @@ static void nr_bwd16(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const
             n3dt_launch_gemm_regions_bf16(M4, ci, co, 1, base, width, ld, wt + L.g1, y, dtv, s);
         }
         // layer_2: d W2[4c + q][:] += d tv_q^T t1 (+ d b2[4c + q]), one product per plane in one launch
-        launch_dw16_x<DwRows<nrt_bf16>, 0>(ci, 2 * ci, (long)M, dtv, DwRows<nrt_bf16>{t1, 2 * ci}, gp->psu2_w[i], (long)4 * 2 * ci, gp->psu2_b[i], s, 4,
-                                           DwPlanes{(long)M * ci, (long)2 * ci, 1, 4});
+        if (dw_ok[2 * i]) n3dt_launch_dw_rowmajor_one(dw, 2 * i, dwpart, s);
+        else
+            launch_dw16_x<DwRows<nrt_bf16>, 0>(ci, 2 * ci, (long)M, dtv, DwRows<nrt_bf16>{t1, 2 * ci}, gp->psu2_w[i], (long)4 * 2 * ci, gp->psu2_b[i], s, 4,
+                                               DwPlanes{(long)M * ci, (long)2 * ci, 1, 4});
         {   // d t1 = (sum_q d tv_q . W2_q) * lrelu'(t1)
             const void* base[4] = {dtv, dtv + (size_t)M * ci, dtv + (size_t)2 * M * ci, dtv + (size_t)3 * M * ci};
             const int width[4] = {ci, ci, ci, ci}, ld[4] = {ci, ci, ci, ci};
             n3dt_launch_gemm_regions_bf16(M, 2 * ci, 4 * ci, 4, base, width, ld, wt + L.g2, t1, dt1, s);
         }
         // layer_1: d W1 += d t1^T x (+ d b1)
-        if (i == 0) launch_dw16<float>(2 * ci, ci, (long)M, dt1, featmap, gp->psu1_w[i], ci, gp->psu1_b[i], s);
+        if (dw_ok[2 * i + 1]) n3dt_launch_dw_rowmajor_one(dw, 2 * i + 1, dwpart, s);
+        else if (i == 0) launch_dw16<float>(2 * ci, ci, (long)M, dt1, featmap, gp->psu1_w[i], ci, gp->psu1_b[i], s);
         else launch_dw16<nrt_bf16>(2 * ci, ci, (long)M, dt1, x16, gp->psu1_w[i], ci, gp->psu1_b[i], s);
         {   // d x = d t1 . W1 + sum_q d hid_q . R_q
             const void* base[5] = {dt1, dhid, dhid + (size_t)M * co, dhid + (size_t)2 * M * co, dhid + (size_t)3 * M * co};
@@ -1078,6 +1101,9 @@ static void nr_bwd16(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const
         hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[0]);
         hipLaunchKernelGGL(nr16_final_kernel, GRID1((size_t)nb * HW * (C0 / 4)), 3 * C0 * sizeof(float), s, nb, HW, C0, (const float*)drgb,
                            p->to_rgb_w[0], dnet_in, d_featmap);
+    }
+    if (any_dw) {  // products that did not take this route left their partial buffers zero: the reduction adds nothing for them
+        n3dt_launch_dw_rowmajor_reduce(dw, 2 * nblk, dwpart, s);
     }
 }
 

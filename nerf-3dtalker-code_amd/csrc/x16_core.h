@@ -440,6 +440,12 @@ __device__ __forceinline__ unsigned x16_tr_lane_offset(const int lane) {
     const int r = lane & 31, h = lane >> 5, q = (r & 15) >> 2, p = r & 3;
     return 64u * (8 * h + q) + 32u * (r >> 4) + 8u * ((p & 1) * 2 + (p >> 1));
 }
+// The same for an image whose rows hold the 32 channels in NATURAL order (row-major maps of the 2-D renderer moved to LDS as
+// they are, train_x16.inc: rowmajor): channels 4p .. 4p+3 are the p-th 8-byte unit.
+__device__ __forceinline__ unsigned x16_tr_lane_offset_natural(const int lane) {
+    const int r = lane & 31, h = lane >> 5, q = (r & 15) >> 2, p = r & 3;
+    return 64u * (8 * h + q) + 32u * (r >> 4) + 8u * p;
+}
 // The reads are issued from inline asm (x16_tr_issue) and retired by ONE s_waitcnt (x16_tr_settle) that names every destination:
 // through the builtin hipcc orders them behind the LDS-DMA stream in flight (s_waitcnt vmcnt(0) in front of the first read of
 // every stage -- the stages still loading are then waited for as well, and the pipeline is one stage deep).
