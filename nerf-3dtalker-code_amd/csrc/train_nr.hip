@@ -441,10 +441,13 @@ __global__ void nrt_rgb_bias_kernel(int nb, int HW, const float* __restrict__ d_
 // (a 3 x co result over up to 10^6 pixels: a reduction, not a GEMM).  Thread = 4 adjacent channels x one pixel lane;
 // block = NRT_WG_PIX consecutive pixels of one image; co in {32, 64, 128, 256}.
 #define NRT_WG_PIX 512
+// db (nullable): the bias gradient db[k] += sum over pixels of d_rgb[img][k][pix] rides on the channel-group-0 threads, which
+// load d_rgb anyway (the stand-alone nrt_rgb_bias_kernel re-read it: one launch per level).
 template <class T>
 __global__ __launch_bounds__(256) void nrt_to_rgb_wgrad_kernel(int HW, int co, const float* __restrict__ d_rgb,
-                                                               const T* __restrict__ net, float* __restrict__ dW) {
+                                                               const T* __restrict__ net, float* __restrict__ dW, float* __restrict__ db) {
     __shared__ float red[256][13];
+    float bsum[3] = {0.0f, 0.0f, 0.0f};
     const int cg = co >> 2, lanes = 256 / cg;
     const int t = threadIdx.x, c4 = (t % cg) * 4, pl = t / cg;
     const int chunks = (HW + NRT_WG_PIX - 1) / NRT_WG_PIX;
@@ -461,6 +464,7 @@ __global__ __launch_bounds__(256) void nrt_to_rgb_wgrad_kernel(int HW, int co, c
         const float gk[3] = {g0, g1, g2};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
+            bsum[k] += gk[k];
             acc[k][0] = fmaf(gk[k], v.x, acc[k][0]);
             acc[k][1] = fmaf(gk[k], v.y, acc[k][1]);
             acc[k][2] = fmaf(gk[k], v.z, acc[k][2]);
@@ -495,11 +499,24 @@ __global__ __launch_bounds__(256) void nrt_to_rgb_wgrad_kernel(int HW, int co, c
         for (int l = 0; l < lanes; ++l) sum += red[l * cg + (c >> 2)][k * 4 + (c & 3)];
         atomicAdd(&dW[(size_t)k * co + c], sum);
     }
+    if (db) {  // uniform over the workgroup: the channel-group-0 threads (one per pixel lane) hold the block's d_rgb sums
+        __syncthreads();
+        if (t % cg == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) red[pl][k] = bsum[k];
+        }
+        __syncthreads();
+        if (t < 3) {
+            float sum = 0.0f;
+            for (int l = 0; l < lanes; ++l) sum += red[l][t];
+            atomicAdd(&db[t], sum);
+        }
+    }
 }
 template <class T>
-static void launch_to_rgb_wgrad(int nb, int HW, int co, const float* d_rgb, const T* net, float* dW, hipStream_t s) {
+static void launch_to_rgb_wgrad(int nb, int HW, int co, const float* d_rgb, const T* net, float* dW, hipStream_t s, float* db = nullptr) {
     const int chunks = (HW + NRT_WG_PIX - 1) / NRT_WG_PIX;
-    hipLaunchKernelGGL(nrt_to_rgb_wgrad_kernel<T>, dim3(nb * chunks), dim3(256), 0, s, HW, co, d_rgb, net, dW);
+    hipLaunchKernelGGL(nrt_to_rgb_wgrad_kernel<T>, dim3(nb * chunks), dim3(256), 0, s, HW, co, d_rgb, net, dW, db);
 }
 
 #define GRID1(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256)
@@ -853,9 +870,20 @@ extern "C" void n3dt_launch_nr_train16_fwd(const N3dtGeom*, int, const N3dtRende
 extern "C" void n3dt_launch_gemm_regions_bf16(int, int, int, int, const void* const*, const int*, const int*, const float*, const void*, void*,
                                               hipStream_t);
 
-// the three transposed / permuted fp32 matrices of one block (nr_train16.h: Nr16Wt)
-__global__ void nr16_pack_wt_kernel(int C, int CO, const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ Wf,
-                                    float* __restrict__ out) {
+// the three transposed / permuted fp32 matrices of every block (nr_train16.h: Nr16Wt); blockIdx.y = block
+struct Nr16PackArgs {
+    const float* W1[N3DT_MAX_BLOCKS];
+    const float* W2[N3DT_MAX_BLOCKS];
+    const float* Wf[N3DT_MAX_BLOCKS];
+    float* out[N3DT_MAX_BLOCKS];
+    int C[N3DT_MAX_BLOCKS], CO[N3DT_MAX_BLOCKS];
+};
+__global__ void nr16_pack_wt_kernel(const Nr16PackArgs a) {
+    const int blk = blockIdx.y, C = a.C[blk], CO = a.CO[blk];
+    const float* __restrict__ W1 = a.W1[blk];
+    const float* __restrict__ W2 = a.W2[blk];
+    const float* __restrict__ Wf = a.Wf[blk];
+    float* __restrict__ out = a.out[blk];
     const Nr16Wt L = nr16_wt_layout(C, CO);
     const size_t n_g3 = (size_t)C * (2 * C + 4 * CO), total = L.g3 + n_g3;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -1010,10 +1038,14 @@ static void nr_bwd16(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const
     float* drgb = reinterpret_cast<float*>(ws + wl.drgb);
     float* dtmp = reinterpret_cast<float*>(ws + wl.dtmp);
     // the transposed weights of every block (weights moved since the last step: packed per call)
-    for (int i = 0; i < nblk; ++i) {
-        const int ci = nr16_ch(C0, i), co = nr16_ch(C0, i + 1);
-        hipLaunchKernelGGL(nr16_pack_wt_kernel, dim3(256), dim3(256), 0, s, ci, co, p->psu1_w[i], p->psu2_w[i], p->feat_w[i],
-                           reinterpret_cast<float*>(ws + wl.wt[i]));
+    {
+        Nr16PackArgs pa;
+        for (int i = 0; i < nblk; ++i) {
+            pa.C[i] = nr16_ch(C0, i); pa.CO[i] = nr16_ch(C0, i + 1);
+            pa.W1[i] = p->psu1_w[i]; pa.W2[i] = p->psu2_w[i]; pa.Wf[i] = p->feat_w[i];
+            pa.out[i] = reinterpret_cast<float*>(ws + wl.wt[i]);
+        }
+        hipLaunchKernelGGL(nr16_pack_wt_kernel, dim3(128, nblk), dim3(256), 0, s, pa);
     }
     // layer_2 / layer_1 weight gradients on the MLP's LDS-transposed kernel (row-major front end, dw_rowmajor.h) where the pixel
     // count allows it: entries 2 i (d W2: the four planes of d_tv as one wide operand against t1) and 2 i + 1 (d W1: d_t1 against x)
@@ -1049,8 +1081,7 @@ static void nr_bwd16(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const
         const float* wt = reinterpret_cast<const float*>(ws + wl.wt[i]);
         const Nr16Wt L = nr16_wt_layout(ci, co);
         // feat_2_rgb[i + 1]: parameter gradients; d_pre
-        launch_to_rgb_wgrad<nrt_bf16>(nb, HW, co, drgb, net, gp->to_rgb_w[i + 1], s);
-        hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[i + 1]);
+        launch_to_rgb_wgrad<nrt_bf16>(nb, HW, co, drgb, net, gp->to_rgb_w[i + 1], s, gp->to_rgb_b[i + 1]);
         hipLaunchKernelGGL(nr16_dpre_kernel, GRID1((size_t)M4 * (co / 8)), 3 * co * sizeof(float), s, nb, HW, co, (const float*)drgb,
                            p->to_rgb_w[i + 1], net, dnet_in, dpre);
         hipLaunchKernelGGL(nr16_blur_adj_q_kernel, GRID1((size_t)M * (co / 8)), 0, s, nb, hin, hin, co, (const nrt_bf16*)dpre, dhid);
@@ -1097,8 +1128,7 @@ static void nr_bwd16(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const
     // stage-0 rgb: feat_2_rgb_list[0](featmap); d featmap = d x_0 + its branch
     {
         const int fs = g->featmap_size, HW = fs * fs;
-        launch_to_rgb_wgrad<float>(nb, HW, C0, drgb, featmap, gp->to_rgb_w[0], s);
-        hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[0]);
+        launch_to_rgb_wgrad<float>(nb, HW, C0, drgb, featmap, gp->to_rgb_w[0], s, gp->to_rgb_b[0]);
         hipLaunchKernelGGL(nr16_final_kernel, GRID1((size_t)nb * HW * (C0 / 4)), 3 * C0 * sizeof(float), s, nb, HW, C0, (const float*)drgb,
                            p->to_rgb_w[0], dnet_in, d_featmap);
     }
