@@ -440,10 +440,10 @@ def extras(ctx):
     rec("cfg2-R_bf16x3_b16", "bf16 MFMA, operands split hi+lo (3 products): the parity-grade MFMA mode; roofline_frac is algorithmic",
         lambda k, w: run_render(ctx, "cfg2", "bf16x3", 16, "R", k, w, prof=False), 6, 2)
     rec("cfg2-R_fp16_b16", "fp16", lambda k, w: run_render(ctx, "cfg2", "fp16", 16, "R", k, w, prof=False), 10, 3)
-    rec("cfg3_train_bf16_b2", "fused bf16 training path", lambda k, w: run_train(ctx, "cfg2", "bf16", 2, k, w), 5, 2)
+    rec("cfg3_train_bf16_b2", "fused bf16 training path", lambda k, w: run_train(ctx, "cfg2", "bf16", 2, k, w), 30, 6)
     rec("cfg3_train_fp32_b2", "exact fp32 training path", lambda k, w: run_train(ctx, "cfg2", "fp32", 2, k, w), 4, 2)
     rec("cfg4_bf16_b4", "bf16", lambda k, w: run_render(ctx, "cfg4", "bf16", 4, "R", k, w, prof=False), 20, 5)
-    rec("cfg4_train_bf16_b2", "fused bf16 training path", lambda k, w: run_train(ctx, "cfg4", "bf16", 2, k, w), 5, 2)
+    rec("cfg4_train_bf16_b2", "fused bf16 training path", lambda k, w: run_train(ctx, "cfg4", "bf16", 2, k, w), 30, 6)
     rec("cfg4_fit_bf16_b1", "single-image fitting iteration (256^2 geometry, as model_Reso32), fused bf16 training path",
         lambda k, w: run_fit(ctx, "cfg4", "bf16", k, w), 10, 3)
     rec("cfg4_fit_fp32_b1", "single-image fitting iteration, exact fp32 training path (the mode for entry-wise camera gradients)",
