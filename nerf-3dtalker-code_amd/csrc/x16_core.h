@@ -234,10 +234,8 @@ struct WeightStream {
         __syncthreads();
         chunk = 0;
         meets = 0;
-#if X16_RV_RAW
         vm_cur = 0;
         vm_prev = 0;
-#endif
         cur_addr = lds_addr0;
         nxt_addr = lds_addr0 + X16_CHUNK_BYTES;
         preload<0>();
@@ -249,29 +247,33 @@ struct WeightStream {
             preload<J + 1>();
         }
     }
-    // The rendezvous.  SHIPPED form (X16_RV_RAW = 0): `__syncthreads()`.  It carries a workgroup-scope release fence, for which
-    // hipcc emits s_waitcnt vmcnt(0) lgkmcnt(0) ahead of the s_barrier; with a three-buffer ring that vmcnt(0) is the wait the
-    // stream needs anyway (chunk meets+1 is the only one in flight), and it measured 1 % FASTER than the counted form in the
-    // inference kernel once the training kernels' loads had been moved off vmcnt (DESIGN 3.6 nulls).
-    // DIAGNOSTIC form (-DX16_RV_RAW=1; not built by the Makefile, not covered by the GPU suite): a raw s_barrier between
-    // compiler barriers behind a COUNTED vmcnt wait.  Chunk meets+1 was issued NBUF-2 rendezvous ago; vector-memory operations
-    // retire in order (loads and stores share vmcnt on gfx9-family parts), so "at most K operations outstanding", K = what
-    // this wave has issued SINCE that chunk's loads, means they have landed.  K = the (NBUF-3) newer chunks' loads plus the
-    // stores the kernel reports through note_stores().  Safety of that form: K must never exceed the true count, so only stores
-    // issued UNCONDITIONALLY at their program point may be reported (dead waves write a dump record); a store added to a kernel
-    // without being reported silently breaks it.  In the shipped form note_stores() compiles to nothing.
-#if X16_RV_RAW
+    // The wait of a rendezvous is COUNTED.  Chunk meets+1 was issued NBUF-2 rendezvous ago; vector-memory operations retire in
+    // order (loads and stores share vmcnt on gfx9-family parts), so "at most K operations outstanding", K = what this wave has
+    // issued SINCE that chunk's loads, means they have landed.  K = the (NBUF-3) newer chunks' loads plus the stores the kernel
+    // reports through note_stores() -- the training kernels write 2-3 KiB per tile, and with a plain vmcnt(0) every rendezvous
+    // also waited for the acknowledgement of the stores issued a tile ago (the write path runs near the HBM write bandwidth
+    // there: the forward with SAVE took 1.58 ms against 0.92 ms without).  Safety: K must never exceed the true count, so only
+    // stores that are issued UNCONDITIONALLY at their program point may be reported (dead waves write a dump record); loads and
+    // stores the kernel does not report only make the wait stricter.  All of this folds at compile time (straight-line code).
+    // THE COUNTED WAIT IS LOAD-BEARING IN EVERY BUILD.  The shipped rendezvous (X16_RV_RAW = 0) follows it with __syncthreads(),
+    // and it is tempting to think that call's workgroup-scope release fence waits vmcnt(0) anyway (round 2's note said so, an
+    // advisor repeated it, and early in round 3 the counted wait was compiled out of the shipped build on that belief).  It does
+    // not: outside thread-group-split mode hipcc emits only the lgkmcnt part for that fence -- the shipped inference kernels show
+    // `s_waitcnt lgkmcnt(..); s_barrier` with no vmcnt wait at 138 of 480 rendezvous (build/nerf_fwd_x16.s) -- so without the
+    // wait below nothing orders a wave's LDS-DMA pieces of chunk meets+1 before the other waves read them.  The race almost
+    // never shows (the chunk was issued two rendezvous earlier) and then shows as a parity failure once in a few hundred runs
+    // (test_split_precision_mode_properties_at_full_size: 7.7e-4 instead of 5e-5).  tests/test_host_cpu.py now checks the
+    // assembly: every rendezvous barrier of a stream kernel has a vmcnt wait in front of it.
+    // -DX16_RV_RAW=1 (diagnostic) replaces __syncthreads() by a raw s_barrier between compiler barriers: what the barrier orders
+    // needs no fence -- this wave's pieces of chunk meets+1 are awaited just above, and a wave's reads of chunk meets-1 (whose
+    // buffer is overwritten next) were consumed by MFMAs a chunk ago.
     int vm_cur = 0, vm_prev = 0;  // reported stores since the last rendezvous / in the period before it
     __device__ __forceinline__ void note_stores(const int n) { vm_cur += n; }
     template <int K>
     __device__ __forceinline__ static void wait_vm() {
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(K) : "memory");
     }
-#else
-    __device__ __forceinline__ void note_stores(const int) {}
-#endif
     __device__ __forceinline__ void rendezvous() {
-#if X16_RV_RAW
         int newer = limit - 2 - meets;  // chunks issued after chunk meets+1: meets+2 .. min(limit-1, meets+NBUF-2)
         newer = newer < 0 ? 0 : (newer > NBUF - 3 ? NBUF - 3 : newer);
         int k = newer * PPW + vm_cur + (NBUF > 3 ? vm_prev : 0);
@@ -280,16 +282,17 @@ struct WeightStream {
             constexpr int K = decltype(k_c)::value;
             if (k == K) wait_vm<K>();  // this wave's pieces of chunk meets+1 have landed
         });
+#if X16_RV_RAW
         __builtin_amdgcn_s_barrier();  // everyone's have; everyone has left chunk meets-1
         asm volatile("" ::: "memory");
-        vm_prev = vm_cur;
-        vm_cur = 0;
 #else
-        __syncthreads();  // (vmcnt(0) + barrier: this wave's pieces of chunk meets+1 have landed, everyone has left chunk meets-1)
+        __syncthreads();
 #endif
 #ifndef X16_NODMA  // diagnostic build: the stream stops after the prologue (results are garbage, the timing is the point)
         if (meets + NBUF - 1 < limit) issue(meets + NBUF - 1);
 #endif
+        vm_prev = vm_cur;
+        vm_cur = 0;
         ++meets;
     }
     // The fragment reads are issued from inline asm so that their completion can be awaited with a COUNTED

@@ -223,3 +223,46 @@ def test_shipped_kernels_stay_within_their_scratch_budget():
                 if allowed[key] is not None:
                     assert int(m.group(1)) <= allowed[key], "%s: %s bytes of scratch, budget %d" % (kernel, m.group(1), allowed[key])
     assert seen > 100
+
+
+def test_every_stream_rendezvous_waits_for_its_lds_dma():
+    """In every shipped kernel that stages data with LDS-DMA (`global_load_lds`), each workgroup barrier must have an explicit
+    `s_waitcnt vmcnt(..)` shortly in front of it.  `__syncthreads()` alone does NOT provide one: outside thread-group-split mode
+    hipcc emits only the lgkmcnt part of its workgroup-scope fence.  Early in round 3 the stream's counted wait was compiled
+    out of the shipped build in the belief that it was redundant; the build then had `s_waitcnt lgkmcnt(..); s_barrier` at 138 of
+    the inference kernel's 480 rendezvous, and a parity test failed once in a few hundred GPU runs."""
+    import glob
+    import re
+    build = os.path.join(REPO, "nerf-3dtalker-code_amd", "build")
+    files = sorted(glob.glob(os.path.join(build, "*.s")))
+    assert files
+    label = re.compile(r"^(_Z\S+|[A-Za-z_][A-Za-z_0-9]*):")
+    n_dma_kernels = n_barriers = 0
+    for path in files:
+        lines = open(path).read().split("\n")
+        kernel, dma = None, set()
+        for line in lines:
+            m = label.match(line)
+            if m:
+                kernel = m.group(1)
+            if "global_load_lds" in line and kernel:
+                dma.add(kernel)
+        n_dma_kernels += len(dma)
+        kernel = None
+        for i, line in enumerate(lines):
+            m = label.match(line)
+            if m:
+                kernel = m.group(1)
+            if kernel in dma and re.search(r"\bs_barrier\b", line) and not line.strip().startswith(";"):
+                n_barriers += 1
+                j, seen, found = i - 1, 0, False
+                while j > 0 and seen < 12:
+                    t = lines[j].strip()
+                    if t and not t.startswith(";") and not t.startswith("."):
+                        seen += 1
+                        if "s_waitcnt" in t and "vmcnt(" in t:
+                            found = True
+                            break
+                    j -= 1
+                assert found, "%s: s_barrier at line %d of %s has no vmcnt wait in front of it" % (kernel, i + 1, os.path.basename(path))
+    assert n_dma_kernels >= 30 and n_barriers >= 1000
