@@ -1,0 +1,80 @@
+"""Randomised check of the 2-D renderer's fused mixed-precision training path (block kernels with the save epilogue,
+backward on sub-pixel planes, multi-region GEMMs, the LDS-transposed weight-gradient kernel on row-major maps) against the exact
+fp32 renderer path on the same inputs, with the volumetric stage held in fp32 (GPU; both through the C ABI).
+
+usage: fuzz_train_nr.py [cases=30] [seed=1]
+Draws featmap sizes 4 .. 64 (pixel counts that are / are not multiples of 32: LDS kernel vs gather kernel; tile counts on either
+side of the latency form's limit), 1 - 4 upsample blocks, batch 1 - 5.  Asserted per tensor of the renderer (and for the
+gradient reaching the volumetric stage, seen through its parameters): cosine >= 0.995, max error <= 6 % of the tensor's scale;
+images within 4e-3."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "nerf-3dtalker-code_amd"))
+
+
+def grads(opt, sd, B, nr_precision, t_rand, dev):
+    from n3dt import HeadNeRFNet, synthetic as syn
+    from n3dt.train import data_losses, disk_mask
+    net = HeadNeRFNet(opt, False, False, train_precision="fp32").to(dev)
+    net.load_state_dict(sd)
+    net.neural_render.train_precision = nr_precision
+    d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in syn.frame_inputs(opt, B).items()}
+    out = net("train", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+              d["batch_Tvecs"], d["batch_inv_inmats"], t_rand=t_rand)["coarse_dict"]
+    P = opt.pred_img_size
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, P), torch.linspace(0, 1, P), indexing="ij")
+    gt = torch.stack([0.3 + 0.4 * xx, 0.6 - 0.3 * yy, 0.5 + 0.2 * xx * yy]).unsqueeze(0).repeat(B, 1, 1, 1).to(dev)
+    terms = data_losses(out, gt, disk_mask(B, P).to(dev))
+    (terms["bg_loss"] + terms["head_loss"] + terms["nonhead_loss"]).backward()
+    g = {n: p.grad.detach().clone() for n, p in net.named_parameters()
+         if n.startswith("neural_render") or n.startswith("fg_CD_predictor.RGB_layer_2") or n.startswith("fg_CD_predictor.FeaExt_module_7")}
+    return out["merge_img"].detach(), out["bg_img"].detach(), g
+
+
+def main():
+    from n3dt import BaseOptions, synthetic as syn
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    bad, worst = 0, {"max": 0.0, "cos": 1.0, "img": 0.0}
+    for case in range(cases):
+        fs = int(rng.choice([4, 5, 6, 8, 12, 16, 24, 32, 64]))
+        nblk = int(rng.choice([1, 2, 3] if fs >= 32 else [1, 2, 3, 4]))
+        B = int(rng.choice([1, 2, 3, 5])) if fs < 64 else int(rng.choice([1, 2]))
+        ns = int(rng.choice([8, 16, 32]))
+        opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": fs << nblk, "num_sample_coarse": ns})
+        sd = syn.make_state_dict(opt, seed=int(rng.integers(0, 1000)), bg_noise=0.1)
+        t_rand = syn.stratified_noise(B, fs * fs, ns, int(rng.integers(0, 1000))).to(dev)
+        i32, b32, g32 = grads(opt, sd, B, "fp32", t_rand, dev)
+        i16, b16, g16 = grads(opt, sd, B, "bf16", t_rand, dev)
+        msg = []
+        ie = max(float((i32 - i16).abs().max()), float((b32 - b16).abs().max()))
+        worst["img"] = max(worst["img"], ie)
+        if ie > 4e-3:
+            msg.append("image %.2e" % ie)
+        for k in g32:
+            a, b = g32[k].double().flatten(), g16[k].double().flatten()
+            scale = float(a.abs().max())
+            if scale == 0.0 and float(b.abs().max()) == 0.0:
+                continue
+            err = float((a - b).abs().max()) / (scale + 1e-30)
+            cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+            worst["max"], worst["cos"] = max(worst["max"], err), min(worst["cos"], cos)
+            if err > 0.06 or cos < 0.995:
+                msg.append("%s err %.3f cos %.5f" % (k, err, cos))
+        M0 = (B + 1) * fs * fs
+        print("case %2d fs %2d blocks %d B %d (pixels of block 0: %6d, %s32)  %s" % (case, fs, nblk, B, M0, "% " if M0 % 32 else "= 0 mod ",
+                                                                                     "OK" if not msg else "FAIL " + "; ".join(msg[:4])), flush=True)
+        bad += bool(msg)
+    print("worst: max err %.3f of scale, cosine %.5f, image %.2e; %d of %d cases failed" % (worst["max"], worst["cos"], worst["img"], bad, cases))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
