@@ -12,6 +12,14 @@
 #include "n3dt_device.h"
 #include "n3dt_layout.h"
 
+// diagnostic: dst[r][c] = bf16(src[r][c]) as fp32, for n = rows * cols elements (cols per row, leading dimensions given)
+__global__ void train_round_bf16_kernel(size_t n, int cols, long ld_src, long ld_dst, const float* __restrict__ src, float* __restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / cols, c = i % cols;
+        dst[r * ld_dst + c] = (float)(__bf16)src[r * ld_src + c];
+    }
+}
+
 #define XR_LD 388  // RGB_layer_0 output (384) | density pre-activation (col 384) | pad
 
 struct TrainSaved {  // float offsets into the saved buffer
@@ -740,12 +748,35 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
             launch_colsum(dcur, 384L, P, 1, 384, gp->bias[l], 0L, s);
         }
         const bool want_cam = d_R || d_T;
+        // DIAGNOSTIC (N3DT_DIAG_PE_BF16, bit 0: round dZ, bit 1: round the weights): the two d-PE products of THIS exact path with
+        // operands rounded to bf16 -- what the fused bf16 path's last product does to the camera gradients, in isolation from
+        // the rounding its dZ has already collected upstream (tools/cam_error_probe.py)
+        static const int diag_pe = [] {
+            const char* e = getenv("N3DT_DIAG_PE_BF16");
+            return e ? atoi(e) : 0;
+        }();
+        const float* dz_pe = dcur;
+        const float* w5_pe = ws + wl.w5p;
+        const float* w0_pe = p->weight[0];
+        long w5_ld = 448, w0_ld = 63 + S + U;
+        if (want_cam && diag_pe && (l == 5 || l == 0)) {
+            static float* wtmp = nullptr;  // diagnostic only: one lazily allocated scratch for the rounded weight columns
+            if (!wtmp) (void)hipMalloc(&wtmp, sizeof(float) * 384 * 64);
+            if (diag_pe & 1) {
+                hipLaunchKernelGGL(train_round_bf16_kernel, dim3(1024), dim3(256), 0, s, (size_t)P * 384, 384, 384, 384, dcur, dnext);
+                dz_pe = dnext;  // (dnext is written by this layer's input-gradient GEMM only after the products below)
+            }
+            if (diag_pe & 2) {
+                if (l == 5) { hipLaunchKernelGGL(train_round_bf16_kernel, dim3(64), dim3(256), 0, s, (size_t)384 * 64, 64, 448, 64, ws + wl.w5p, wtmp); w5_pe = wtmp; w5_ld = 64; }
+                else { hipLaunchKernelGGL(train_round_bf16_kernel, dim3(64), dim3(256), 0, s, (size_t)384 * 63, 63, 63 + S + U, 64, p->weight[0], wtmp); w0_pe = wtmp; w0_ld = 64; }
+            }
+        }
         if (want_cam && l == 5) {  // d PE from the skip layer: dH5 W5'[:, 0:64]
-            Gemm32 q = mk(P, 64, 384, dcur, 384, 0, ws + wl.w5p, 448, 1, ws + wl.dpe, 64);
+            Gemm32 q = mk(P, 64, 384, dz_pe, 384, 0, w5_pe, w5_ld, 1, ws + wl.dpe, 64);
             n3dt_gemm32(q, s);
         }
         if (want_cam && l == 0) {  // += dH0 W0[:, 0:63]
-            Gemm32 q = mk(P, 63, 384, dcur, 384, 0, p->weight[0], 63 + S + U, 1, ws + wl.dpe, 64);
+            Gemm32 q = mk(P, 63, 384, dz_pe, 384, 0, w0_pe, w0_ld, 1, ws + wl.dpe, 64);
             q.accumulate = 1;
             n3dt_gemm32(q, s);
             if (d_R) (void)hipMemsetAsync(d_R, 0, sizeof(float) * 9 * B, s);
