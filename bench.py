@@ -464,8 +464,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "bf16x3"])
     ap.add_argument("--rays", default="R", choices=["R", "N"],
                     help="R: rays = featmap_size^2 (reference-faithful); N: 512^2 rays, feature stage only")
-    ap.add_argument("--mode", default="render", choices=["render", "train"],
-                    help="render: forward-only (BASELINE config 2, the headline); train: fwd+loss+bwd+Adam (config 3)")
+    ap.add_argument("--mode", default="render", choices=["render", "train", "fit"],
+                    help="render: forward-only (BASELINE config 2, the headline); train: fwd+loss+bwd+Adam (config 3); "
+                         "fit: one single-image fitting iteration (B = 1, gradients to codes + camera, frozen network)")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
                     help="BASELINE.json geometry: cfg2 (headline: 64x64 rays x 64 samples -> 512^2; cfg3 with --mode train), "
                          "cfg4 (32x32 rays x 64 samples -> 256^2, 4 heads per GPU), cfg5 (HR: 32x32 rays x 96 samples -> 1024^2)")
@@ -490,6 +491,17 @@ def main():
     seen = ctx.ranks_seen()
     assert seen == args.gpus, "the collective backend connects %d ranks, --gpus says %d" % (seen, args.gpus)
 
+    if args.mode == "fit":
+        tp = "bf16" if args.precision == "bf16" else "fp32"
+        r = run_fit(ctx, args.config, tp, args.steps, args.warmup)
+        if ctx.rank == 0:
+            fs, ns, pred = GEOMETRY[args.config]
+            print(json.dumps({"metric": "fitting iterations/sec @%d^2 x %d samples/ray" % (pred, ns), "value": r["frames_per_s"], "unit": "iterations/s",
+                              "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": tp, "data": "synthetic",
+                              "config": {"workload": r["workload"]}}), flush=True)
+        ctx.close()
+        return
     if args.mode == "train":
         tp = "bf16" if args.precision == "bf16" else "fp32"
         B = min(args.batch, 2)

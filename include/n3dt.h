@@ -223,7 +223,10 @@ int n3dt_neural_render_fwd_reuse(const N3dtGeom* g, int nb, int precision, const
  *   Differentiates NetWorks/models.py:62-87, NetWorks/utils.py:268-309, NetWorks/HeadNeRFNet.py:84-112,149-152.
  *   Camera gradients (the fitting use-case, FittingSingleImage_new.py:826-859): when d_R [B,3,3] and/or d_T [B,3]
  *   are non-NULL they receive dL/d(batch_Rmats), dL/d(batch_Tvecs); xy, R, T, Kinv (and t_rand if the forward
- *   used it) must then be the forward's inputs.  Pass NULL for all seven to skip that work. */
+ *   used it) must then be the forward's inputs.  Pass NULL for all seven to skip that work.
+ *   `grads` == NULL (both n3dt_render_bwd and n3dt_neural_render_bwd): the network is FROZEN, as in single-image fitting
+ *   (FittingSingleImage_new.py:826-859 optimises codes and cameras only) -- no parameter gradient is computed, only the
+ *   gradients of the inputs (d_bg_featmap must then be NULL too). */
 size_t n3dt_render_train_saved_bytes(const N3dtGeom* g);
 size_t n3dt_render_train_workspace_bytes(const N3dtGeom* g);
 int n3dt_render_train_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, const N3dtMlpParams* p,

@@ -411,12 +411,15 @@ extern "C" int n3dt_render_bwd(const N3dtGeom* g, int precision, const N3dtMlpPa
     int rc = check_train_geom(g);
     if (rc) return rc;
     if (precision != N3DT_F32 && precision != N3DT_BF16) return fail(N3DT_EINVAL, "training precision must be N3DT_F32 or N3DT_BF16");
-    if (!p || !grads || !shape || !appea || !saved || !workspace) return fail(N3DT_EINVAL, "n3dt_render_bwd: NULL argument");
+    if (!p || !shape || !appea || !saved || !workspace) return fail(N3DT_EINVAL, "n3dt_render_bwd: NULL argument");
     if (!d_merge_feat && !d_fg_feat && !d_bg_alpha) return fail(N3DT_EINVAL, "n3dt_render_bwd: no incoming gradient");
     if (d_merge_feat && !bg_featmap) return fail(N3DT_EINVAL, "n3dt_render_bwd: d_merge_feat needs bg_featmap");
     if (g->audio_dim > 0 && !audio) return fail(N3DT_EINVAL, "n3dt_render_bwd: audio is NULL but audio_dim > 0");
-    for (int l = 0; l < N3DT_MLP_LAYERS; ++l)
-        if (!grads->weight[l] || !grads->bias[l]) return fail(N3DT_EINVAL, "n3dt_render_bwd: NULL gradient pointer");
+    // grads == NULL: the network is frozen (single-image fitting) -- no parameter gradient is computed, only d codes / d cameras
+    if (grads)
+        for (int l = 0; l < N3DT_MLP_LAYERS; ++l)
+            if (!grads->weight[l] || !grads->bias[l]) return fail(N3DT_EINVAL, "n3dt_render_bwd: NULL gradient pointer");
+    if (!grads && d_bg_featmap) return fail(N3DT_EINVAL, "n3dt_render_bwd: grads == NULL (frozen network) but d_bg_featmap given");
     if (saved_bytes < n3dt_render_train_saved_bytes(g)) return fail(N3DT_EWORKSPACE, "n3dt_render_bwd: saved buffer too small");
     if (workspace_bytes < n3dt_render_train_workspace_bytes(g)) return fail(N3DT_EWORKSPACE, "n3dt_render_bwd: workspace too small");
     if ((d_R || d_T) && (!xy || !R || !T || !Kinv)) return fail(N3DT_EINVAL, "n3dt_render_bwd: camera gradients need xy, R, T, Kinv");
@@ -465,7 +468,7 @@ extern "C" int n3dt_neural_render_bwd(const N3dtGeom* g, int nb, int precision, 
                                       void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_nr(g, nb);
     if (rc) return rc;
-    if (!p || !grads || !featmap || !d_img || !saved || !d_featmap || !workspace)
+    if (!p || !featmap || !d_img || !saved || !d_featmap || !workspace)  // (grads == NULL: frozen renderer, only d_featmap is wanted)
         return fail(N3DT_EINVAL, "n3dt_neural_render_bwd: NULL argument");
     if (saved_bytes < n3dt_neural_render_train_saved_bytes(g, nb)) return fail(N3DT_EWORKSPACE, "neural render saved buffer too small");
     if (workspace_bytes < n3dt_neural_render_train_workspace_bytes(g, nb)) return fail(N3DT_EWORKSPACE, "neural render workspace too small");

@@ -249,7 +249,7 @@ __global__ void train_bg_b2_grad_kernel(N3dtGeom g, const float* __restrict__ ra
         }
         if (d_bg && d_merge) d_bg[(size_t)c * g.n_rays + ray] += acc;
     }
-    atomicAdd(&db2[c], accb);
+    if (db2) atomicAdd(&db2[c], accb);  // (nullptr: frozen network)
 }
 
 // one wave per ray: compositing backward (see DESIGN.md for the derivation)
@@ -332,6 +332,14 @@ __global__ void train_composite_bwd_kernel(N3dtGeom g, const float* __restrict__
 }
 
 #define CAM_RAYS 64
+// Rays per workgroup of the camera backward kernels: CAM_RAYS where there are many rays (each block ends in 12 atomics on the
+// same 12 addresses per frame: one block per 4 rays meant 2 048 atomics per address at config 3), fewer where there are few -- a
+// single 32 x 32 frame (single-image fitting) was 16 workgroups on 256 CUs: 348 us for 65 536 points.
+static inline int n3dt_cam_rays_per_block(int n_rays, int batch) {
+    int r = CAM_RAYS;
+    while (r > 4 && (long)((n_rays + r - 1) / r) * batch < 512) r >>= 1;
+    return r;
+}
 // Camera backward (the single-image fitting use-case): one wave per ray.
 //   p_s = T + (d l) z_s,  dist_s = (z_{s+1} - z_s) l,  d = w/|w|,  w = R c,  c = Kinv [x, y, 1],  l = -1/d_z
 //   PE rows: [p, sin(2^k p), cos(2^k p)]  ->  dp = dPE_p + sum_k 2^k (cos * dPE_sin - sin * dPE_cos)
@@ -341,15 +349,15 @@ __global__ void train_camera_bwd_kernel(N3dtGeom g, const float* __restrict__ xy
                                         const float* __restrict__ T, const float* __restrict__ Kinv,
                                         const float* __restrict__ t_rand, const float* __restrict__ cat5,
                                         const float* __restrict__ dpe, const float* __restrict__ dxr, float* __restrict__ d_R,
-                                        float* __restrict__ d_T) {
-    // block = CAM_RAYS consecutive rays of ONE frame (blockIdx.y), 4 waves taking rays in turn; the 12 results are summed
+                                        float* __restrict__ d_T, const int cam_rays) {
+    // block = cam_rays (<= CAM_RAYS) consecutive rays of ONE frame (blockIdx.y), 4 waves taking rays in turn; the 12 results are summed
     // in registers and LDS and leave as 12 atomics per block (one block per 4 rays meant 2 048 atomics per address)
     __shared__ float cam_red[4][12];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y, Ns = g.n_samples;
     float sum_R[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sum_T[3] = {0.f, 0.f, 0.f};
-    const int ray_end = min(g.n_rays, (int)(blockIdx.x + 1) * CAM_RAYS);
-    for (int ray = blockIdx.x * CAM_RAYS + wave; ray < ray_end; ray += 4) {
+    const int ray_end = min(g.n_rays, (int)(blockIdx.x + 1) * cam_rays);
+    for (int ray = blockIdx.x * cam_rays + wave; ray < ray_end; ray += 4) {
     const long rayg = (long)b * g.n_rays + ray;
     const float* Rb = R + b * 9;
     const float* Kb = Kinv + b * 9;
@@ -502,7 +510,8 @@ static void launch_colsum(const float* X, long ldx, int rows_per_frame, int fram
 __global__ void train_fold_bwd_kernel(N3dtMlpParams p, N3dtMlpGrads gp, int S, int A, int U, int B, const float* __restrict__ shape,
                                       const float* __restrict__ appea, const float* __restrict__ audio,
                                       const float* __restrict__ dfold, float* __restrict__ d_shape, float* __restrict__ d_appea,
-                                      float* __restrict__ d_audio) {
+                                      float* __restrict__ d_audio, const int frozen) {
+    // frozen != 0: the network's parameters take no gradient (single-image fitting): only the code gradients are formed
     const int which = blockIdx.x, f = blockIdx.y, t = threadIdx.x;
     const int in0 = N3DT_PE_DIM + S + U, in5 = N3DT_PE_DIM + S + N3DT_HID, inr = N3DT_HID + A;
     const int layer = which == 0 ? 0 : (which == 1 ? 5 : 10);
@@ -517,7 +526,8 @@ __global__ void train_fold_bwd_kernel(N3dtMlpParams p, N3dtMlpGrads gp, int S, i
     const int per = (nout + FOLDB_ROWGROUPS - 1) / FOLDB_ROWGROUPS;
     const int o0 = blockIdx.z * per, o1 = min(nout, o0 + per);
     // bias gradient (each frame adds its share)
-    for (int o = o0 + t; o < o1; o += blockDim.x) atomicAdd(&gp.bias[layer][o], sdb[o]);
+    if (!frozen)
+        for (int o = o0 + t; o < o1; o += blockDim.x) atomicAdd(&gp.bias[layer][o], sdb[o]);
     // code gradients and latent weight columns
     for (int i = t; i < ncode; i += blockDim.x) {
         float code;
@@ -527,7 +537,7 @@ __global__ void train_fold_bwd_kernel(N3dtMlpParams p, N3dtMlpGrads gp, int S, i
 #pragma unroll 4
         for (int o = o0; o < o1; ++o) {
             acc = fmaf(p.weight[layer][(size_t)o * ld + col0 + i], sdb[o], acc);
-            atomicAdd(&gp.weight[layer][(size_t)o * ld + col0 + i], sdb[o] * code);
+            if (!frozen) atomicAdd(&gp.weight[layer][(size_t)o * ld + col0 + i], sdb[o] * code);
         }
         if (which == 2) { if (d_appea) atomicAdd(&d_appea[(size_t)f * A + i], acc); }
         else if (i < S) { if (d_shape) atomicAdd(&d_shape[(size_t)f * S + i], acc); }
@@ -559,8 +569,9 @@ static void launch_fold_bwd(const N3dtMlpParams* p, const N3dtMlpGrads* gp, int 
         if (d_appea) (void)hipMemsetAsync(d_appea, 0, sizeof(float) * (size_t)B * A, s);
         if (d_audio && U > 0) (void)hipMemsetAsync(d_audio, 0, sizeof(float) * (size_t)B * U, s);
     }
-    hipLaunchKernelGGL(train_fold_bwd_kernel, dim3(3, B, FOLDB_ROWGROUPS), dim3(256), 0, s, *p, *gp, S, A, U, B, shape, appea, audio, dfold, d_shape,
-                       d_appea, d_audio);
+    static const N3dtMlpGrads no_grads = {};
+    hipLaunchKernelGGL(train_fold_bwd_kernel, dim3(3, B, FOLDB_ROWGROUPS), dim3(256), 0, s, *p, gp ? *gp : no_grads, S, A, U, B, shape, appea, audio, dfold,
+                       d_shape, d_appea, d_audio, gp ? 0 : 1);
 }
 
 // scatter the packed gradients back: dW5[:,0:63] += dW5'[:,0:63]; dW5[:,63+S:] += dW5'[:,64:]; dWr0 += dWc[0:384]; dwd += dWc[384]
@@ -694,9 +705,10 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
     // ---- head: RGB_layer_2 once per ray + merge (models.py:82, HeadNeRFNet.py:103-112)
     hipLaunchKernelGGL(train_head_bwd_kernel, dim3((unsigned)((Rr + HB_RAYS - 1) / HB_RAYS)), dim3(256), 0, s, *g, p->weight[11], p->bias[11], bg_featmap, d_merge,
                        d_fg, d_ba, dfg_total, ws + wl.dgray, ws + wl.dwsum, (long)Rr);
-    hipLaunchKernelGGL(train_bg_b2_grad_kernel, dim3((g->n_rays + BG_RAYS - 1) / BG_RAYS), dim3(256), 0, s, *g, saved + sv.ray, d_merge, dfg_total, d_bg_featmap,
-                       gp->bias[11]);
-    {   // dW2[256][192] += dfg_total^T Gray
+    if (gp || d_bg_featmap)
+        hipLaunchKernelGGL(train_bg_b2_grad_kernel, dim3((g->n_rays + BG_RAYS - 1) / BG_RAYS), dim3(256), 0, s, *g, saved + sv.ray, d_merge, dfg_total,
+                           d_bg_featmap, gp ? gp->bias[11] : nullptr);
+    if (gp) {   // dW2[256][192] += dfg_total^T Gray
         Gemm32 q = mk(256, 192, (int)Rr, dfg_total, 256, 1, saved + sv.ray, N3DT_PART_STRIDE, 1, gp->weight[11], 192);
         set_grad_split(q, Rr);
         n3dt_gemm32(q, s);
@@ -708,9 +720,11 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
     {
         Gemm32 q = mk(P, 384, 192, dG, 192, 0, p->weight[10], 384 + A, 1, dxr, XR_LD);  // dX = dG Wr1[:, 0:384]
         n3dt_gemm32(q, s);
-        Gemm32 w = mk(192, 384, P, dG, 192, 1, saved + sv.xr, XR_LD, 1, gp->weight[10], 384 + A);  // dWr1[:, 0:384] += dG^T X
-        set_grad_split(w, P);
-        n3dt_gemm32(w, s);
+        if (gp) {  // (gp == nullptr: frozen network, only input gradients are wanted)
+            Gemm32 w = mk(192, 384, P, dG, 192, 1, saved + sv.xr, XR_LD, 1, gp->weight[10], 384 + A);  // dWr1[:, 0:384] += dG^T X
+            set_grad_split(w, P);
+            n3dt_gemm32(w, s);
+        }
         launch_colsum(dG, 192L, ppf, B, 192, dfold + n3dt_bias_offset(10), (long)N3DT_FOLD_STRIDE, s);
     }
     // ---- RGB_layer_0 | density: dH7 = dXR Wc, gated by relu(H7)
@@ -718,18 +732,21 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
         Gemm32 q = mk(P, 384, 385, dxr, XR_LD, 0, ws + wl.wc, 384, 1, dha, 384);
         q.gate = hptr(7); q.ldgate = hld(7); q.gate_act = G32_ACT_RELU;
         n3dt_gemm32(q, s);
-        Gemm32 w = mk(385, 384, P, dxr, XR_LD, 1, hptr(7), hld(7), 1, ws + wl.dwc, 384);
-        set_grad_split(w, P);
-        n3dt_gemm32(w, s);
+        if (gp) {
+            Gemm32 w = mk(385, 384, P, dxr, XR_LD, 1, hptr(7), hld(7), 1, ws + wl.dwc, 384);
+            set_grad_split(w, P);
+            n3dt_gemm32(w, s);
+        }
         // bias grads of RGB_layer_0 (cols 0..383) and density (col 384): one frame group of all rows
-        launch_colsum(dxr, (long)XR_LD, P, 1, 385, ws + wl.bc, 0L, s);  // [d br0 (384) | d bd] into the packed scratch, copied out below
+        if (gp) launch_colsum(dxr, (long)XR_LD, P, 1, 385, ws + wl.bc, 0L, s);  // [d br0 (384) | d bd] into the packed scratch, copied out below
     }
     // ---- trunk, layers 7..0.  `dcur` = dL/dH_l (already gated by relu'(H_l))
     float* dcur = dha;
     float* dnext = dhb;
     for (int l = 7; l >= 0; --l) {
-        // parameter gradients of layer l
-        if (l == 5) {
+        // parameter gradients of layer l (none for a frozen network)
+        if (!gp) {
+        } else if (l == 5) {
             Gemm32 w = mk(384, 448, P, dcur, 384, 1, cat5, 448, 1, ws + wl.dw5p, 448);
             set_grad_split(w, P);
             n3dt_gemm32(w, s);
@@ -744,7 +761,7 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
         }
         if (l == 0 || l == 5) {
             launch_colsum(dcur, 384L, ppf, B, 384, dfold + n3dt_bias_offset(l), (long)N3DT_FOLD_STRIDE, s);
-        } else {
+        } else if (gp) {
             launch_colsum(dcur, 384L, P, 1, 384, gp->bias[l], 0L, s);
         }
         const bool want_cam = d_R || d_T;
@@ -781,8 +798,9 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
             n3dt_gemm32(q, s);
             if (d_R) (void)hipMemsetAsync(d_R, 0, sizeof(float) * 9 * B, s);
             if (d_T) (void)hipMemsetAsync(d_T, 0, sizeof(float) * 3 * B, s);
-            hipLaunchKernelGGL(train_camera_bwd_kernel, dim3((g->n_rays + CAM_RAYS - 1) / CAM_RAYS, B), dim3(256), 0, s, *g, xy, Rm, Tv, Kinv, t_rand, cat5,
-                               ws + wl.dpe, dxr, d_R, d_T);
+            const int cr = n3dt_cam_rays_per_block(g->n_rays, B);
+            hipLaunchKernelGGL(train_camera_bwd_kernel, dim3((g->n_rays + cr - 1) / cr, B), dim3(256), 0, s, *g, xy, Rm, Tv, Kinv, t_rand, cat5,
+                               ws + wl.dpe, dxr, d_R, d_T, cr);
         }
         if (l == 0) break;
         // input gradient: dH_{l-1} = (dH_l W_l) * relu'(H_{l-1})
@@ -792,8 +810,9 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
         n3dt_gemm32(q, s);
         float* t = dcur; dcur = dnext; dnext = t;
     }
-    hipLaunchKernelGGL(train_unpack_grads_kernel, dim3((384 * 448 + 255) / 256), dim3(256), 0, s, *gp, S, ws + wl.dw5p, ws + wl.dwc,
-                       ws + wl.bc);
+    if (gp)
+        hipLaunchKernelGGL(train_unpack_grads_kernel, dim3((384 * 448 + 255) / 256), dim3(256), 0, s, *gp, S, ws + wl.dw5p, ws + wl.dwc,
+                           ws + wl.bc);
     launch_fold_bwd(p, gp, S, A, U, B, shape, appea, audio, dfold, d_shape, d_appea, d_audio, s);
 }
 

@@ -1055,13 +1055,15 @@ static void nr_bwd16(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const
     for (int i = 0; i < nblk; ++i) {
         const int ci = nr16_ch(C0, i);
         const long hh = (long)g->featmap_size << i, M = (long)nb * hh * hh;
-        dw[2 * i] = N3dtDwRm{dtv, ci, 4, (size_t)M * ci, saved + sv.t1[i], 2 * ci, M, 4 * ci, 2 * ci, gp->psu2_w[i], 2 * ci, ci, gp->psu2_b[i]};
-        dw[2 * i + 1] = N3dtDwRm{dt1, 2 * ci, 1, 0, i > 0 ? (const void*)(saved + sv.net[i - 1]) : nullptr, ci, M, 2 * ci, ci, gp->psu1_w[i], ci, 0,
-                                 gp->psu1_b[i]};
+        // (gp == nullptr: frozen renderer -- single-image fitting -- no parameter gradient at all, only the dX chain)
+        dw[2 * i] = N3dtDwRm{dtv, ci, 4, (size_t)M * ci, saved + sv.t1[i], 2 * ci, M, 4 * ci, 2 * ci, gp ? gp->psu2_w[i] : nullptr, 2 * ci, ci,
+                             gp ? gp->psu2_b[i] : nullptr};
+        dw[2 * i + 1] = N3dtDwRm{dt1, 2 * ci, 1, 0, i > 0 ? (const void*)(saved + sv.net[i - 1]) : nullptr, ci, M, 2 * ci, ci,
+                                 gp ? gp->psu1_w[i] : nullptr, ci, 0, gp ? gp->psu1_b[i] : nullptr};
         static const bool off_env = [] { const char* e = getenv("N3DT_NR_DW_LDS"); return e && atoi(e) == 0; }();
         const bool off = off_env || 2 * nblk > N3DT_DW_RM_MAX;  // (the reduction launch carries at most N3DT_DW_RM_MAX products)
-        dw_ok[2 * i] = !off && n3dt_dw_rowmajor_ok(&dw[2 * i]);
-        dw_ok[2 * i + 1] = !off && i > 0 && n3dt_dw_rowmajor_ok(&dw[2 * i + 1]);  // (block 0's x is the fp32 feature map)
+        dw_ok[2 * i] = gp && !off && n3dt_dw_rowmajor_ok(&dw[2 * i]);
+        dw_ok[2 * i + 1] = gp && !off && i > 0 && n3dt_dw_rowmajor_ok(&dw[2 * i + 1]);  // (block 0's x is the fp32 feature map)
         any_dw = any_dw || dw_ok[2 * i] || dw_ok[2 * i + 1];
     }
     float* dwpart = reinterpret_cast<float*>(ws + wl.dwpart);
@@ -1081,12 +1083,13 @@ static void nr_bwd16(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const
         const float* wt = reinterpret_cast<const float*>(ws + wl.wt[i]);
         const Nr16Wt L = nr16_wt_layout(ci, co);
         // feat_2_rgb[i + 1]: parameter gradients; d_pre
-        launch_to_rgb_wgrad<nrt_bf16>(nb, HW, co, drgb, net, gp->to_rgb_w[i + 1], s, gp->to_rgb_b[i + 1]);
+        if (gp) launch_to_rgb_wgrad<nrt_bf16>(nb, HW, co, drgb, net, gp->to_rgb_w[i + 1], s, gp->to_rgb_b[i + 1]);
         hipLaunchKernelGGL(nr16_dpre_kernel, GRID1((size_t)M4 * (co / 8)), 3 * co * sizeof(float), s, nb, HW, co, (const float*)drgb,
                            p->to_rgb_w[i + 1], net, dnet_in, dpre);
         hipLaunchKernelGGL(nr16_blur_adj_q_kernel, GRID1((size_t)M * (co / 8)), 0, s, nb, hin, hin, co, (const nrt_bf16*)dpre, dhid);
         // feat_layers: d Wf += d hid^T ps (+ d bf), over all four planes' pixels
-        if (i == 0)
+        if (!gp) {
+        } else if (i == 0)
             launch_dw16_x<DwPs<float>, 1>(co, ci, (long)M, dhid, DwPs<float>{y, featmap, (long)M, ci}, gp->feat_w[i], ci, gp->feat_b[i], s, 1,
                                           DwPlanes{(long)M * co, 0, 0, 1});
         else if (co > 32)
@@ -1101,7 +1104,7 @@ static void nr_bwd16(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const
         }
         // layer_2: d W2[4c + q][:] += d tv_q^T t1 (+ d b2[4c + q]), one product per plane in one launch
         if (dw_ok[2 * i]) n3dt_launch_dw_rowmajor_one(dw, 2 * i, dwpart, s);
-        else
+        else if (gp)
             launch_dw16_x<DwRows<nrt_bf16>, 0>(ci, 2 * ci, (long)M, dtv, DwRows<nrt_bf16>{t1, 2 * ci}, gp->psu2_w[i], (long)4 * 2 * ci, gp->psu2_b[i], s, 4,
                                                DwPlanes{(long)M * ci, (long)2 * ci, 1, 4});
         {   // d t1 = (sum_q d tv_q . W2_q) * lrelu'(t1)
@@ -1111,7 +1114,8 @@ static void nr_bwd16(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const
         }
         // layer_1: d W1 += d t1^T x (+ d b1)
         if (dw_ok[2 * i + 1]) n3dt_launch_dw_rowmajor_one(dw, 2 * i + 1, dwpart, s);
-        else if (i == 0) launch_dw16<float>(2 * ci, ci, (long)M, dt1, featmap, gp->psu1_w[i], ci, gp->psu1_b[i], s);
+        else if (!gp) {
+        } else if (i == 0) launch_dw16<float>(2 * ci, ci, (long)M, dt1, featmap, gp->psu1_w[i], ci, gp->psu1_b[i], s);
         else launch_dw16<nrt_bf16>(2 * ci, ci, (long)M, dt1, x16, gp->psu1_w[i], ci, gp->psu1_b[i], s);
         {   // d x = d t1 . W1 + sum_q d hid_q . R_q
             const void* base[5] = {dt1, dhid, dhid + (size_t)M * co, dhid + (size_t)2 * M * co, dhid + (size_t)3 * M * co};
@@ -1128,7 +1132,7 @@ static void nr_bwd16(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const
     // stage-0 rgb: feat_2_rgb_list[0](featmap); d featmap = d x_0 + its branch
     {
         const int fs = g->featmap_size, HW = fs * fs;
-        launch_to_rgb_wgrad<float>(nb, HW, C0, drgb, featmap, gp->to_rgb_w[0], s, gp->to_rgb_b[0]);
+        if (gp) launch_to_rgb_wgrad<float>(nb, HW, C0, drgb, featmap, gp->to_rgb_w[0], s, gp->to_rgb_b[0]);
         hipLaunchKernelGGL(nr16_final_kernel, GRID1((size_t)nb * HW * (C0 / 4)), 3 * C0 * sizeof(float), s, nb, HW, C0, (const float*)drgb,
                            p->to_rgb_w[0], dnet_in, d_featmap);
     }
@@ -1175,8 +1179,10 @@ static void nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N
         const int hin = h / 2, M = nb * hin * hin, M4 = nb * h * h, HW = h * h;
         const T* net = saved + sv.net[i];
         // rgb = rgb_prev_up + feat_2_rgb[i+1](net): parameter grads, then d net (gated by lrelu'(net))
-        launch_to_rgb_wgrad<T>(nb, HW, co, drgb, net, gp->to_rgb_w[i + 1], s);
-        hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[i + 1]);
+        if (gp) {  // (gp == nullptr: frozen renderer, only the input gradient is wanted)
+            launch_to_rgb_wgrad<T>(nb, HW, co, drgb, net, gp->to_rgb_w[i + 1], s);
+            hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[i + 1]);
+        }
         // d net: from the rgb branch (+ from the next stage's input gradient, already in dnet when i < nblk-1)
         if (i == nblk - 1) {
             hipLaunchKernelGGL(nrt_to_rgb_bwd_kernel<T>, GRID1((size_t)M4 * (co / 4)), 3 * co * sizeof(float), s, nb, HW, co, drgb,
@@ -1189,7 +1195,7 @@ static void nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N
         }
         // feat conv: net = lrelu(bl Wf^T + bf)
         {
-            conv_bwd_w<T, T>(co, ci, M4, (const T*)dnet, saved + sv.bl[i], gp->feat_w[i], gp->feat_b[i], s);
+            if (gp) conv_bwd_w<T, T>(co, ci, M4, (const T*)dnet, saved + sv.bl[i], gp->feat_w[i], gp->feat_b[i], s);
             conv_bwd_x<T>(M4, ci, co, dnet, p->feat_w[i], 0, nullptr, bufB, ws_f + wl.wt, s);  // d bl
         }
         // blur adjoint -> d ps (bufC), then un-shuffle into d tv (bufB, gated) and the residual gradient (bufA)
@@ -1199,12 +1205,13 @@ static void nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N
         T* dxres = bufA;  // [M][ci]
         // layer_2: tv = lrelu(t1 W2^T + b2)
         {
-            conv_bwd_w<T, T>(4 * ci, 2 * ci, M, (const T*)dtv, saved + sv.t1[i], gp->psu2_w[i], gp->psu2_b[i], s);
+            if (gp) conv_bwd_w<T, T>(4 * ci, 2 * ci, M, (const T*)dtv, saved + sv.t1[i], gp->psu2_w[i], gp->psu2_b[i], s);
             conv_bwd_x<T>(M, 2 * ci, 4 * ci, dtv, p->psu2_w[i], 1, saved + sv.t1[i], bufC, ws_f + wl.wt, s);  // d t1, gated by lrelu'(t1)
         }
         // layer_1: t1 = lrelu(x W1^T + b1);  dx = dt1 W1 + residual gradient
         {
-            if (i == 0) conv_bwd_w<T, float>(2 * ci, ci, M, (const T*)bufC, featmap, gp->psu1_w[i], gp->psu1_b[i], s);
+            if (!gp) {
+            } else if (i == 0) conv_bwd_w<T, float>(2 * ci, ci, M, (const T*)bufC, featmap, gp->psu1_w[i], gp->psu1_b[i], s);
             else conv_bwd_w<T, T>(2 * ci, ci, M, (const T*)bufC, saved + sv.net[i - 1], gp->psu1_w[i], gp->psu1_b[i], s);
             conv_bwd_x<T>(M, ci, 2 * ci, bufC, p->psu1_w[i], 2, dxres, dxres, ws_f + wl.wt, s);  // dx = dt1 W1 + residual gradient
         }
@@ -1221,8 +1228,10 @@ static void nr_bwd(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const N
         const int fs = g->featmap_size, HW = fs * fs;
         hipLaunchKernelGGL(nrt_blur_adj_planar_kernel, GRID1((size_t)nb * 3 * 4 * HW), 0, s, nb * 3, 2 * fs, 2 * fs, drgb, dtmp);
         hipLaunchKernelGGL(nrt_bilinear_adj_kernel, GRID1((size_t)nb * 3 * HW), 0, s, nb * 3, fs, fs, dtmp, drgb);
-        launch_to_rgb_wgrad<float>(nb, HW, C, drgb, featmap, gp->to_rgb_w[0], s);
-        hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[0]);
+        if (gp) {
+            launch_to_rgb_wgrad<float>(nb, HW, C, drgb, featmap, gp->to_rgb_w[0], s);
+            hipLaunchKernelGGL(nrt_rgb_bias_kernel, dim3(64, 3), dim3(256), 0, s, nb, HW, drgb, gp->to_rgb_b[0]);
+        }
         hipLaunchKernelGGL(nrt_to_rgb_bwd_kernel<T>, GRID1((size_t)nb * HW * (C / 4)), 3 * C * sizeof(float), s, nb, HW, C, drgb,
                            p->to_rgb_w[0], (const T*)nullptr, dnet, 1);
         const size_t n = (size_t)nb * HW * C;

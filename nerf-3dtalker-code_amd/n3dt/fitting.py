@@ -58,7 +58,9 @@ class FittingState:
         if self.opt_cam:
             groups += [{"params": [self.delta_EulurAngles], "lr": init_learn_rate * 0.1},
                        {"params": [self.delta_Tvecs], "lr": init_learn_rate * 0.1}]
-        optimizer = torch.optim.Adam(groups, betas=(0.9, 0.999))
+        # (PyTorch's single-kernel implementation of the same update where the variables live on a GPU: five tiny tensors are
+        # otherwise ~30 launches per iteration of a loop that is host-bound)
+        optimizer = torch.optim.Adam(groups, betas=(0.9, 0.999), fused=self.iden_offset.is_cuda)
         scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda epoch: 0.1 ** (epoch / step_decay))
         return optimizer, scheduler
 

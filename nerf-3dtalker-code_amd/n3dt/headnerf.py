@@ -272,6 +272,15 @@ class _RenderFn(torch.autograd.Function):
         geom = ctx.geom
         # gradient buffers: slices of the module's persistent arena (zeroed by one fill per backward pass, and what a
         # multi-GPU step all-reduces in place) -- or fresh zeroed buffers when the arena cannot be used (see FlatGrads.hand_out)
+        if not (any(ctx.needs_input_grad[12:]) or ctx.needs_input_grad[11]):
+            # FROZEN network (single-image fitting optimises codes and cameras only, FittingSingleImage_new.py:826-859): no
+            # parameter gradient is wanted, so none is computed -- the weight-gradient stage is a quarter of a fitting iteration
+            _, d_shape, d_appea, d_audio, d_R, d_T = ops.render_bwd(geom, ops.mlp_params(ws, bs), None, shape_c, appea_c, audio_c, bg,
+                                                                    d_merge.contiguous(), ctx.saved, ctx.cam, ctx.prec, frozen=True)
+            ctx.saved = None
+            if d_T is not None:
+                d_T = d_T.view(ctx.T_shape)
+            return (None, None, None, None, None, None, d_R, d_T, d_shape, d_appea, d_audio, None, *([None] * len(ctx.mlp_shapes)))
         views = ctx.net._hand_out_grads(ctx.param_objs)
         if views is None:
             gws, gbs, d_bg_out = _zeros_like_many(ws), _zeros_like_many(bs), None
@@ -375,14 +384,19 @@ class _NeuralRenderFn(torch.autograd.Function):
                 sizes = ctx.split + [1]
                 d_img = torch.cat([torch.zeros(n, 3, P, P, dtype=torch.float32, device=fm.device) if d is None else d.float()
                                    for d, n in zip(d_imgs, sizes)])
-        owner = ctx.nr._arena_owner
-        views = owner._hand_out_grads(ctx.param_objs) if owner is not None else None
-        gt = _zeros_like_many(list(tensors)) if views is None else [v.view(t.shape) for v, t in zip(views, tensors)]
-        d_feat = ops.neural_render_bwd(ctx.geom, nb, ctx.nr._rparams_from(tensors), ctx.nr._rparams_from(gt), fm,
-                                       d_img, ctx.saved, ctx.prec)
+        n_lead = 5 + (0 if ctx.split is None else len(ctx.split))
+        if not any(ctx.needs_input_grad[n_lead:]):  # frozen renderer (fitting): the input gradient only
+            d_feat = ops.neural_render_bwd(ctx.geom, nb, ctx.nr._rparams_from(tensors), None, fm, d_img, ctx.saved, ctx.prec)
+            grads = [None] * len(ctx.shapes)
+        else:
+            owner = ctx.nr._arena_owner
+            views = owner._hand_out_grads(ctx.param_objs) if owner is not None else None
+            gt = _zeros_like_many(list(tensors)) if views is None else [v.view(t.shape) for v, t in zip(views, tensors)]
+            d_feat = ops.neural_render_bwd(ctx.geom, nb, ctx.nr._rparams_from(tensors), ctx.nr._rparams_from(gt), fm,
+                                           d_img, ctx.saved, ctx.prec)
+            grads = [g.view(s) for g, s in zip(gt, ctx.shapes)]
+            del gt, views
         ctx.saved = None
-        grads = [g.view(s) for g, s in zip(gt, ctx.shapes)]
-        del gt, views
         if ctx.split is None:
             return (None, None, None, d_feat, None, *grads)
         fs, C = ctx.nr.featmap_size, ctx.nr.n_feat
@@ -390,7 +404,9 @@ class _NeuralRenderFn(torch.autograd.Function):
         for n, shp in zip(ctx.split, ctx.merged_shapes):
             d_merged.append(d_feat[lo:lo + n].view(shp))
             lo += n
-        d_bg = ops.chw_to_hwc(d_feat[nb - 1].view(fs * fs, C), fs * fs, C).view(1, C, fs, fs)  # [N_r, C] -> [C, N_r]
+        d_bg = None
+        if ctx.needs_input_grad[4]:
+            d_bg = ops.chw_to_hwc(d_feat[nb - 1].view(fs * fs, C), fs * fs, C).view(1, C, fs, fs)  # [N_r, C] -> [C, N_r]
         return (None, None, None, None, d_bg, *d_merged, *grads)
 
 

@@ -309,13 +309,16 @@ def render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape, appea, audio, 
     return out, saved
 
 
-def render_bwd(geom, params, grads, shape, appea, audio, bg_featmap, d_merge, saved, cam=None, precision=0, d_bg=None):
+def render_bwd(geom, params, grads, shape, appea, audio, bg_featmap, d_merge, saved, cam=None, precision=0, d_bg=None, frozen=False):
     """Backward of render_train_fwd.  `grads` (MlpParams struct of zeroed tensors) is accumulated into.
     cam = (xy, R, T, Kinv, t_rand) requests camera gradients.
     Returns (d_bg_featmap [C,Nr], d_shape, d_appea, d_audio, d_R, d_T)."""
     dev = d_merge.device
     B, Nr, C = geom.batch, geom.n_rays, geom.feat_nc
-    if d_bg is None:  # (a caller-provided buffer -- a slice of the gradient arena -- is already zeroed)
+    if frozen:  # grads is None: no parameter gradient, no d_bg_featmap
+        assert grads is None
+        d_bg = None
+    elif d_bg is None:  # (a caller-provided buffer -- a slice of the gradient arena -- is already zeroed)
         d_bg = torch.zeros(C, Nr, dtype=torch.float32, device=dev)
     # the three code gradients side by side in one allocation: the library zeroes adjacent buffers with one launch
     S_, A_, U_ = geom.shape_dim, geom.appea_dim, geom.audio_dim
@@ -332,7 +335,8 @@ def render_bwd(geom, params, grads, shape, appea, audio, bg_featmap, d_merge, sa
     wbytes = lib().n3dt_render_train_workspace_bytes(ctypes.byref(geom))
     ws = WORKSPACE.get("train", wbytes, dev)
     check(lib().n3dt_render_bwd(
-        ctypes.byref(geom), precision, ctypes.byref(params), ctypes.byref(grads), _ptr(shape), _ptr(appea), _ptr(audio), _ptr(bg_featmap),
+        ctypes.byref(geom), precision, ctypes.byref(params), None if grads is None else ctypes.byref(grads), _ptr(shape), _ptr(appea), _ptr(audio),
+        _ptr(bg_featmap),
         _ptr(d_merge), None, None, _ptr(saved), saved.numel(), _ptr(d_bg), _ptr(d_shape), _ptr(d_appea), _ptr(d_audio),
         *cam_ptrs, _ptr(d_R), _ptr(d_T), _ptr(ws), wbytes, _stream()), "n3dt_render_bwd")
     return d_bg, d_shape, d_appea, d_audio, d_R, d_T
@@ -357,6 +361,7 @@ def neural_render_bwd(geom, nb, rparams, rgrads, featmap, d_img, saved, precisio
     d_feat = torch.empty_like(featmap)
     wbytes = lib().n3dt_neural_render_train_workspace_bytes(ctypes.byref(geom), nb)
     ws = WORKSPACE.get("nr_train", wbytes, dev)
-    check(lib().n3dt_neural_render_bwd(ctypes.byref(geom), nb, precision, ctypes.byref(rparams), ctypes.byref(rgrads), _ptr(featmap), _ptr(d_img),
+    check(lib().n3dt_neural_render_bwd(ctypes.byref(geom), nb, precision, ctypes.byref(rparams), None if rgrads is None else ctypes.byref(rgrads),
+                                       _ptr(featmap), _ptr(d_img),
                                        _ptr(saved), saved.numel(), _ptr(d_feat), _ptr(ws), wbytes, _stream()), "n3dt_neural_render_bwd")
     return d_feat

@@ -260,3 +260,43 @@ def test_bf16_and_fp32_training_converge_to_the_same_loss():
     # bf16-vs-fp32 difference 2.7e-2 .. 8.1e-2 while two fp32 runs differ by 0.9e-2 .. 1.2e-2 there).  The bf16 run must stay
     # within 5e-3 on average, and 99 % of its pixels within 0.1, of the fp32 run beyond three times that floor.
     assert s16[0] <= 5e-3 + 3.0 * s32[0] and s16[2] <= 0.1 + 3.0 * s32[2]
+
+
+@pytest.mark.parametrize("train_precision", ["fp32", "bf16"])
+def test_frozen_network_backward_gives_the_same_input_gradients(train_precision):
+    """Single-image fitting optimises codes and cameras through a FROZEN network (FittingSingleImage_new.py:826-859).  With no
+    parameter requiring grad the backward takes the `grads == NULL` route of the C ABI -- no weight-gradient stage, the per-frame
+    bias sums of dZ_0 / dZ_5 / the RGB rows from a row-sum pass over the saved tiles -- and must return the same d codes / d cameras
+    as the full backward, through the coarse pass and the 2-D renderer."""
+    from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
+    from n3dt.train import fused_data_losses, disk_mask
+    opt = BaseOptions({"featmap_size": 16, "featmap_nc": 256, "pred_img_size": 64, "num_sample_coarse": 40})
+    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
+    B = 2
+    t_rand = syn.stratified_noise(B, 256, 40, seed=3).to(dev())
+    mask = disk_mask(B, 64).to(dev())
+    gt = torch.full((B, 3, 64, 64), 0.5, device=dev())
+    names = ("audiostyle", "shape_code", "appea_code", "batch_Rmats", "batch_Tvecs")
+
+    def grads(frozen):
+        net = HeadNeRFNet(opt, False, False, train_precision=train_precision).to(dev())
+        net.load_state_dict(sd, strict=True)
+        if frozen:
+            for p in net.parameters():
+                p.requires_grad_(False)
+        d = to_dev(syn.frame_inputs(opt, B))
+        for k in names:
+            d[k] = d[k].clone().requires_grad_(True)
+        out = net("train", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+                  d["batch_Tvecs"], d["batch_inv_inmats"], t_rand=t_rand)
+        fused_data_losses(out["coarse_dict"], gt, mask)["total_loss"].backward()
+        torch.cuda.synchronize()
+        assert all(p.grad is None for p in net.parameters()) == frozen
+        return {k: d[k].grad.clone() for k in names}
+
+    full, froz = grads(False), grads(True)
+    for k in names:
+        scale = float(full[k].abs().max())
+        err = float((full[k] - froz[k]).abs().max()) / scale
+        # the row sums are formed in a different order (fp32 atomics either way); everything else is the same arithmetic
+        assert err <= 2e-4, "%s: frozen vs full backward differ by %.2e of scale" % (k, err)
