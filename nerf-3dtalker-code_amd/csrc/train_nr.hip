@@ -1060,7 +1060,8 @@ static void nr_bwd16(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const
                              gp ? gp->psu2_b[i] : nullptr};
         dw[2 * i + 1] = N3dtDwRm{dt1, 2 * ci, 1, 0, i > 0 ? (const void*)(saved + sv.net[i - 1]) : nullptr, ci, M, 2 * ci, ci,
                                  gp ? gp->psu1_w[i] : nullptr, ci, 0, gp ? gp->psu1_b[i] : nullptr};
-        static const bool off_env = [] { const char* e = getenv("N3DT_NR_DW_LDS"); return e && atoi(e) == 0; }();
+        const char* lds_env = getenv("N3DT_NR_DW_LDS");  // (read per call: a test flips it in-process)
+        const bool off_env = lds_env && atoi(lds_env) == 0;
         const bool off = off_env || 2 * nblk > N3DT_DW_RM_MAX;  // (the reduction launch carries at most N3DT_DW_RM_MAX products)
         dw_ok[2 * i] = gp && !off && n3dt_dw_rowmajor_ok(&dw[2 * i]);
         dw_ok[2 * i + 1] = gp && !off && i > 0 && n3dt_dw_rowmajor_ok(&dw[2 * i + 1]);  // (block 0's x is the fp32 feature map)
