@@ -351,3 +351,44 @@ def test_standalone_renderer_module_is_differentiable():
     for n in gp16:
         scale = float(gp16[n].abs().max()) + 1e-30
         assert float((gp16[n] - gp16g[n]).abs().max()) / scale <= 1e-3, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(64, 256, 512, 3), (16, 256, 64, 2), (4, 256, 32, 5), (12, 256, 96, 1), (6, 256, 48, 2)])
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_matrix_pipe_blur_agrees_with_the_per_output_blur(geom, precision):
+    """The Blur + LeakyReLU + feat_2_rgb stage of the fused 16-bit renderer has two forms: the 3 x 3 stencil as an MFMA over a
+    4 x 8 tile's halo (csrc/nr_blur_mfma.inc, the default where the map sizes allow it) and one thread per pixel x 8 channels
+    (`N3DT_NR_BLUR_MFMA=0`, and every shape the first does not take: the 6 x 6 map here).  Same products, fp32 accumulation in a
+    different order: the images agree to fp32 rounding (a 16-bit rounding of an activation flips too rarely to show); both sit in
+    the 16-bit band around the exact fp32 renderer.  Covers image borders on every side of a tile (4 x 4 maps are ALL border), a map size that is not a power of
+    two, several maps per call."""
+    from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
+    fs, nc, out, nb = geom
+    opt = BaseOptions({"featmap_size": fs, "featmap_nc": nc, "pred_img_size": out, "num_sample_coarse": 8})
+    sd = syn.make_state_dict(opt, seed=5, bg_noise=0.1)
+    gen = torch.Generator().manual_seed(fs + nb)
+    x = (0.7 * torch.randn(nb, fs, fs, nc, generator=gen)).to(dev())  # ray-major maps, as the volumetric stage hands them over
+
+    def run(prec, env):
+        net = HeadNeRFNet(opt, False, False, precision=prec).to(dev())
+        net.load_state_dict(sd, strict=True)
+        if env is not None:
+            os.environ["N3DT_NR_BLUR_MFMA"] = env
+        try:
+            with torch.no_grad():
+                img = net.neural_render.render_hwc(x, prec)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("N3DT_NR_BLUR_MFMA", None)
+        return img
+
+    ref = run("fp32", None)
+    a, b = run(precision, "1"), run(precision, "0")
+    assert a.shape == b.shape == ref.shape == (nb, 3, out, out)
+    assert bool(torch.isfinite(a).all())
+    band = 2e-2 if precision == "bf16" else 3e-3
+    ea, eb, d = float((a - ref).abs().max()), float((b - ref).abs().max()), float((a - b).abs().max())
+    print("%s %s: mfma vs fp32 %.2e, per-output vs fp32 %.2e, mfma vs per-output %.2e (mean %.2e)" % (geom, precision, ea, eb, d, float((a - b).abs().mean())))
+    assert ea <= band and eb <= band
+    assert d <= 5e-6 and float((a - b).abs().mean()) <= 5e-7  # (measured 2.4e-7 / 4e-8: exact products, nine-term fp32 sums)
