@@ -392,3 +392,41 @@ def test_matrix_pipe_blur_agrees_with_the_per_output_blur(geom, precision):
     print("%s %s: mfma vs fp32 %.2e, per-output vs fp32 %.2e, mfma vs per-output %.2e (mean %.2e)" % (geom, precision, ea, eb, d, float((a - b).abs().mean())))
     assert ea <= band and eb <= band
     assert d <= 5e-6 and float((a - b).abs().mean()) <= 5e-7  # (measured 2.4e-7 / 4e-8: exact products, nine-term fp32 sums)
+
+
+def _random_free_shapes(n, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        n_x, n_y = int(rng.randint(1, 48)), int(rng.randint(1, 40))
+        out.append((n_x, n_y, int(rng.choice([1, 2, 3, 5])), int(rng.choice([1, 2, 7, 16, 31, 32, 33, 48, 63, 64, 65, 96]))))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", _random_free_shapes(10, 2026))
+def test_render_features_on_random_free_ray_sets(shape):
+    """Ten seeded random ray-set shapes (1 .. 1 833 rays per frame, 1 .. 96 samples: single-sample rays, ragged and whole sample
+    blocks, ray counts on both sides of every tile and workgroup multiple) in the two parity-grade modes against the oracle's
+    feature stage, train-mode jitter included."""
+    from n3dt import synthetic as syn
+    from oracle import oracle as orc
+    n_x, n_y, batch, ns = shape
+    opt, sd, inp = _free_ray_case(n_x, n_y, batch, ns, seed=n_x * 97 + n_y)
+    n_r = n_x * n_y
+    d = to_dev(inp)
+    t_rand = syn.stratified_noise(batch, n_r, ns, seed=3)
+    ref = orc.forward(sd, opt, inp, t_rand=t_rand, skip_neural_render=True)
+    for precision in ("fp32", "bf16x3"):
+        net = build_net(opt, sd, precision)
+        f = feats(net, d, t_rand.to(dev()), want_merge=False, want_weight=True)
+        assert f["fg_feat"].shape == (batch, n_r, 256)
+        e_f = np.abs(f["fg_feat"].permute(0, 2, 1).cpu().numpy() - ref["fg_feat"]).max()
+        e_a = np.abs(f["bg_alpha"].cpu().numpy()[:, None] - ref["bg_alpha"]).max()
+        print("random free rays %s %s: fg_feat %.2e bg_alpha %.2e" % (shape, precision, e_f, e_a))
+        # (one or two samples per ray: a sample spans the whole 6-unit slab and alpha = 1 - exp(-sigma * dist) multiplies sigma's
+        #  rounding by it -- tools/fuzz_parity.py's alpha band for the split-operand mode)
+        tol = FREE_FEAT_TOL[precision] * (2.0 if ns <= 2 and precision == "bf16x3" else 1.0)
+        assert e_f <= tol and e_a <= tol
+        w = f["weight"].cpu().numpy()
+        np.testing.assert_allclose(w.sum(-1) + f["bg_alpha"].cpu().numpy(), 1.0, atol=2e-5)
