@@ -471,3 +471,34 @@ def test_hierarchical_pass_on_random_geometries(case):
     # (the fine planes are an inverse CDF of the coarse weights: a weight error moves a plane by error / pdf, so the fine image
     #  inherits the coarse pass's rounding amplified -- the band of test_hierarchical_pass)
     assert e_c <= 1e-4 and e_f <= 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(1, 5), (2, 12), (3, 17), (1, 64), (2, 100), (5, 33)])
+def test_fused_loss_tail_on_odd_image_sizes(size):
+    """n3dt_loss_fwd / n3dt_loss_bwd at image sizes whose pixel count is and is not a multiple of four (the kernels read 16 bytes
+    per lane where they can) against the plain PyTorch form of the same three terms (`n3dt.train.data_losses`, itself pinned to
+    the reference by the `loss` fixture): values, the kernel's own total, and both image gradients; NaNs in the rendered image,
+    mask values at exactly 0.5, a black background."""
+    from n3dt.train import data_losses, fused_data_losses
+    B, P = size
+    gen = torch.Generator().manual_seed(100 * B + P)
+    merge = torch.rand(B, 3, P, P, generator=gen)
+    merge[0, 1, P // 2, P // 3] = float("nan")
+    bg = torch.rand(1, 3, P, P, generator=gen)
+    gt = torch.rand(B, 3, P, P, generator=gen)
+    mask = torch.rand(B, 1, P, P, generator=gen)
+    mask[0, 0, 0, 0] = 0.5
+    for bg_value in (1.0, 0.0):
+        m1, b1 = merge.clone().to(dev()).requires_grad_(True), bg.clone().to(dev()).requires_grad_(True)
+        m2, b2 = merge.clone().to(dev()).requires_grad_(True), bg.clone().to(dev()).requires_grad_(True)
+        t = fused_data_losses({"merge_img": m1, "bg_img": b1}, gt.to(dev()), mask.to(dev()), bg_value=bg_value)
+        r = data_losses({"merge_img": m2, "bg_img": b2}, gt.to(dev()), mask.to(dev()), bg_value=bg_value)
+        for k in ("bg_loss", "head_loss", "nonhead_loss"):
+            np.testing.assert_allclose(float(t[k].detach()), float(r[k].detach()), rtol=5e-6)
+        ref_total = r["bg_loss"] + r["head_loss"] + r["nonhead_loss"]
+        np.testing.assert_allclose(float(t["total_loss"].detach()), float(ref_total.detach()), rtol=5e-6)
+        t["total_loss"].backward()
+        ref_total.backward()
+        np.testing.assert_allclose(m1.grad.cpu().numpy(), torch.nan_to_num(m2.grad, nan=0.0).cpu().numpy(), atol=1e-9, rtol=1e-5)
+        np.testing.assert_allclose(b1.grad.cpu().numpy(), b2.grad.cpu().numpy(), atol=1e-9, rtol=1e-5)
