@@ -377,7 +377,9 @@ __global__ __launch_bounds__(256) void ray_head_kernel(N3dtGeom g, int bpr, int 
 // The FMA kernel is VALU-bound (1 536 FMAs per thread): 100 us per 32 768 rays, 2 % of the render step.
 typedef __bf16 rh_bf16x8 __attribute__((ext_vector_type(8)));
 #define RH_RAYS 32
-__global__ __launch_bounds__(256) void ray_head_mfma_kernel(N3dtGeom g, int bpr, int bs, const float* __restrict__ part,
+// __launch_bounds__(256, 4): four waves per SIMD = four workgroups per CU (128 registers, no spill; hipcc took 160 unasked, three
+// workgroups per CU: 2 048 workgroups at 16 frames then ran in 2.7 rounds instead of 2): 64 -> 55 us per 65 536 rays.
+__global__ __launch_bounds__(256, 4) void ray_head_mfma_kernel(N3dtGeom g, int bpr, int bs, const float* __restrict__ part,
                                                             const float* __restrict__ wlocal, const float* __restrict__ tail,
                                                             const float* __restrict__ bg_featmap, int bg_hwc,
                                                             float* __restrict__ fg_feat, float* __restrict__ bg_alpha,

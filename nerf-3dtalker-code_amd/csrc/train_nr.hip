@@ -624,8 +624,14 @@ struct DwPlanes {
     long dy_plane, out_plane;
     int db_plane, db_stride;
 };
+// Two waves per SIMD for the 8-tile instantiations that fit 256 registers without a spill (hipcc takes 272 unasked: ONE wave per
+// SIMD); the pixel-split gather of the planes form (DwPs, PM = 0) spills 18 under that cap and is left alone.
+template <class XL>
+struct nrt_dw16_is_rows { static constexpr bool value = false; };
+template <class T>
+struct nrt_dw16_is_rows<DwRows<T>> { static constexpr bool value = true; };
 template <int TO, int TI, class XL, int PM = 0>
-__global__ __launch_bounds__(256) void nrt_dw16_kernel(int co, int ci, long K, const nrt_bf16* __restrict__ dY, const XL X,
+__global__ __launch_bounds__(256, (TO * TI >= 8 && (PM == 1 || nrt_dw16_is_rows<XL>::value)) ? 2 : 1) void nrt_dw16_kernel(int co, int ci, long K, const nrt_bf16* __restrict__ dY, const XL X,
                                                        float* __restrict__ out, long ldo, long chunk, float* __restrict__ db, const DwPlanes pl) {
     // db (nullable): the bias gradient db[c] += sum over pixels of dY[pix][c] rides along on the workgroups of the first input
     // tile group -- the column sums of the fragments they load anyway (a separate column-sum pass re-read dY: 9 launches, 0.26 ms
