@@ -254,10 +254,12 @@ def run_train(ctx, config, train_precision, batch, steps, warmup, audio2style_bu
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    t_enqueued = time.perf_counter() - t0  # host time to ENQUEUE the steps (no synchronisation inside the loop)
     ctx.barrier()
     elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
     return {
         "elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "frames_per_s": ctx.world * batch * steps / elapsed,
+        "host_enqueue_ms_per_step": 1e3 * t_enqueued / steps,
         "allreduce_bytes_per_step": reducer.bytes_per_step() if reducer is not None else 0,
         "allreduce_buckets": [a.numel * 4 for a in reducer.arenas] if reducer is not None else [],
         "allreduce_launched_inside_backward": reducer.hook_launches if reducer is not None else 0,
@@ -424,6 +426,8 @@ def extras(ctx):
             r = fn(steps, warmup)
             e = {"workload": r["workload"] + " [%s]" % note, "ms_per_step": r["ms_per_step"], "frames_per_s": r["frames_per_s"],
                  "steps": steps, "warmup": warmup}
+            if "host_enqueue_ms_per_step" in r:
+                e["host_enqueue_ms_per_step"] = r["host_enqueue_ms_per_step"]
             if "frac" in r:
                 e["fused_mlp_kernel_ms"] = r["kern_ms"]
                 e["roofline_frac"] = r["frac"]
@@ -517,6 +521,7 @@ def main():
                            "parallelism": "frames sharded over %d rank(s); gradients averaged in place in two flat buckets per step "
                                           "(HeadNeRFNet's arena, launched from inside backward; then a 21.5 M-parameter Audio2style "
                                           "stand-in)" % ctx.world,
+                           "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"],
                            "allreduce_bytes_per_step": r["allreduce_bytes_per_step"], "allreduce_buckets": r["allreduce_buckets"],
                            "allreduce_launched_inside_backward": r["allreduce_launched_inside_backward"],
                            "cpus_bound_per_rank": ctx.cpus_bound, "ranks_seen_by_backend": seen},

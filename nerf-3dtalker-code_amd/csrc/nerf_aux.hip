@@ -549,7 +549,19 @@ extern "C" void n3dt_launch_ray_head(const N3dtGeom* g, int bpr, int bs, const f
 extern "C" void n3dt_launch_ray_head_rec(const N3dtGeom* g, int bpr, int bs, const float* part, const float* wlocal,
                                          const float* tail, const float* bg_featmap, float* fg_feat, float* bg_alpha, float* depth,
                                          float* weight, float* merge_feat, float* rayrec, hipStream_t stream) {
+    // (the fused mixed-precision training forward: RGB_layer_2 on the matrix pipe with both factors split hi + lo, as in the 16-bit
+    //  render modes -- the FMA form took 41 us for 8 192 rays, 1 536 FMAs per thread; N3DT_TRAIN_HEAD_FMA=1 keeps it)
     const long nrays_total = (long)g->batch * g->n_rays;
+    static const bool fma = [] {
+        const char* e = getenv("N3DT_TRAIN_HEAD_FMA");
+        return e && atoi(e) != 0;
+    }();
+    if (!fma) {
+        const int grid = (int)((nrays_total + RH_RAYS - 1) / RH_RAYS);
+        hipLaunchKernelGGL(ray_head_mfma_kernel, dim3(grid), dim3(256), 0, stream, *g, bpr, bs, part, wlocal, tail,
+                           merge_feat ? bg_featmap : nullptr, 0, fg_feat, bg_alpha, depth, weight, merge_feat, rayrec);
+        return;
+    }
     const int grid = (int)((nrays_total + HEAD_RAYS - 1) / HEAD_RAYS);
     hipLaunchKernelGGL(ray_head_kernel, dim3(grid), dim3(256), 0, stream, *g, bpr, bs, part, wlocal, tail,
                        merge_feat ? bg_featmap : nullptr, 0, fg_feat, bg_alpha, depth, weight, merge_feat, rayrec);
