@@ -868,6 +868,8 @@ class HeadNeRFNet(nn.Module):
         fs, C = self.featmap_size, self.featmap_nc
         xy = batch_xy if batch_xy.dtype == torch.float32 else batch_xy.float()
         geom = self._geom(B, n_r, xy)
+        if self._grad_arena is not None and torch._C._current_graph_task_id() == -1:
+            self._grad_arena.end_pass()  # (a backward that raised never told the arena that its pass was over)
         layers = self.fg_CD_predictor.layers()
         mlp = [m.weight for m in layers] + [m.bias for m in layers]
         audio = audiostyle if self.audio_dim > 0 else torch.zeros(B, 0, device=xy.device)

@@ -42,6 +42,9 @@ class FlatGrads:
         self.numel = sum(p.numel() for p in self.params)
         self.touched = False      # a backward handed slices out since the last reduction / zero()
         self._in_pass = False     # slices handed out in the backward pass now running (see hand_out)
+        self._pass_id = None      # autograd graph-task id of that pass
+        self._handed = set()
+        self.in_flight = False    # a collective is reading / writing `flat` (set by GradReducer): nothing may be handed out
 
     def matches(self, params):
         ps = [p for p in params if p.requires_grad]
@@ -60,6 +63,14 @@ class FlatGrads:
     def zero(self):
         self.flat.zero_()
         self.touched = False
+        self.end_pass()
+
+    def end_pass(self):
+        """Forget the hand-outs of the last backward pass.  The engine's final callback does this when a pass ends normally;
+        a backward that RAISED (an out-of-memory batch a training loop skips) never runs it, so hand_out also compares the
+        autograd graph-task id, and HeadNeRFNet calls this at the start of every differentiable forward."""
+        self._in_pass, self._pass_id = False, None
+        self._handed = set()
 
     def hand_out(self, params):
         """Zeroed gradient slices for `params`, for a backward kernel to accumulate into and return -- or None when the arena
@@ -67,13 +78,16 @@ class FlatGrads:
         backward passes: autograd must add, not overwrite), or its slice was already handed out in this pass (the module was
         applied twice in one graph).  The whole arena is zeroed by ONE fill at the first hand-out of a pass."""
         idx = [self.index.get(id(p)) for p in params]
-        if any(i is None for i in idx):
+        if any(i is None for i in idx) or self.in_flight:
             return None
+        task = torch._C._current_graph_task_id()
+        if self._in_pass and task != self._pass_id:
+            self.end_pass()  # the pass that set the flag never finished (its backward raised): this is a new one
         if not self._in_pass:
             if any(p.grad is not None for p in self.params):
                 return None
             self.flat.zero_()
-            self._in_pass, self._handed = True, set()
+            self._in_pass, self._pass_id, self._handed = True, task, set()
             # cleared when the engine finishes this backward pass
             torch.autograd.Variable._execution_engine.queue_callback(self._end_pass)
         if any(i in self._handed for i in idx):
@@ -83,11 +97,13 @@ class FlatGrads:
         return [self.view(i) for i in idx]
 
     def _end_pass(self):
-        self._in_pass = False
+        self.end_pass()
 
-    def adopt(self):
+    def adopt(self, assign_missing=True):
         """Make every parameter's `.grad` its slice: gradients living elsewhere are copied in (one multi-tensor copy),
-        missing ones read as zeros (every rank reduces the same layout)."""
+        missing ones read as zeros (every rank reduces the same layout).  assign_missing=False leaves the `.grad` of a
+        parameter without a gradient None (its slice still reads zero): a collective launched from inside backward must not
+        turn a slice it is reducing into a tensor autograd would accumulate a LATE gradient into."""
         src, dst, missing = [], [], []
         for i, p in enumerate(self.params):
             g = p.grad
@@ -96,6 +112,8 @@ class FlatGrads:
             v = self.view(i)
             if g is None:
                 missing.append(v)
+                if not assign_missing:
+                    continue
             else:
                 src.append(g.detach())
                 dst.append(v)
@@ -171,49 +189,116 @@ class GradReducer:
 
     A bucket's collective is launched (async) from a post-accumulate-grad hook as soon as every parameter that received a
     gradient in the PREVIOUS step has received one in this step; whatever was not launched by then (the first step, a step
-    whose set of used parameters changed) is launched by wait().  wait() joins the collectives, scales by 1/world and leaves
-    every parameter's `.grad` as a slice of its bucket."""
+    whose set of used parameters shrank) is launched by wait().  wait() joins the collectives, scales by 1/world and leaves
+    every parameter's `.grad` as a slice of its bucket.
 
-    def __init__(self, buckets, world=None, group=None):
+    What happens to a gradient that arrives while its bucket is already being reduced:
+      * a parameter that did NOT fire last step (the used set grew: a sub-network was unfrozen, a branch was taken for the
+        first time): its slice went out as zeros and its `.grad` was left None, so autograd gives it a fresh tensor, not a
+        slice under reduction.  wait() copies such LATE gradients into their slices and reduces those slices in a second
+        round of collectives, after the first has completed.  Every rank sees the same late set (the ranks run the same graph).
+      * a parameter whose gradient is ALREADY in the bucket (a second backward() before wait(): gradient accumulation; or a
+        `.grad` kept alive through zero_grad(set_to_none=False)): autograd accumulates in place into a slice the collective
+        is reading and writing.  That cannot be repaired afterwards: wait() raises RuntimeError.  Accumulate under
+        `with reducer.no_sync():` (hooks launch nothing there) and run the last backward of the step outside it.
+
+    force=True registers the hooks at world size 1 too (a one-rank process group exercises the same stream ordering between
+    the backward kernels and the collective as N ranks do; tests/test_gpu_round4.py)."""
+
+    def __init__(self, buckets, world=None, group=None, force=False):
         self.group = group
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.active = self.world > 1 or force
         self.arenas = [b if isinstance(b, FlatGrads) else _arena_for(list(b)) for b in buckets]
         self.expected = [None] * len(self.arenas)   # ids of the parameters that fired last step
         self.fired = [set() for _ in self.arenas]
+        self.late = [dict() for _ in self.arenas]    # id -> parameter that fired after its bucket's launch
         self.work = [None] * len(self.arenas)
         self.launch_order = []
         self.hook_launches = 0   # collectives started from inside backward (the overlapped ones)
+        self.late_rounds = 0     # second-round collectives wait() had to run
+        self.error = None
+        self._sync = True
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for bi, a in enumerate(self.arenas):
                 for p in a.params:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
 
     def _make_hook(self, bi):
         def hook(p):
+            if not self._sync:
+                return
             f = self.fired[bi]
+            if self.work[bi] is not None:
+                a = self.arenas[bi]
+                if id(p) in f or id(p) in self.late[bi] or a.is_view(a.index[id(p)], p.grad):
+                    self.error = ("a gradient was accumulated into bucket %d while its all-reduce was in flight (a second "
+                                  "backward() before wait(), or a .grad kept by zero_grad(set_to_none=False)); accumulate "
+                                  "under `with reducer.no_sync():`" % bi)
+                else:
+                    self.late[bi][id(p)] = p
+                return
             f.add(id(p))
             exp = self.expected[bi]
-            if exp is not None and self.work[bi] is None and len(f) == len(exp) and f == exp:
-                self._launch(bi)
+            if exp is not None and len(f) == len(exp) and f == exp:
+                self._launch(bi, from_hook=True)
                 self.hook_launches += 1
         return hook
 
-    def _launch(self, bi):
+    def no_sync(self):
+        """Context manager for gradient accumulation: backward passes inside it launch no collective and are not counted;
+        the step's LAST backward runs outside it, followed by wait()."""
+        reducer = self
+
+        class _NoSync:
+            def __enter__(self_):
+                assert all(w is None for w in reducer.work), "no_sync() entered with a collective in flight: call wait() first"
+                reducer._sync = False
+
+            def __exit__(self_, *exc):
+                reducer._sync = True
+                reducer.fired = [set() for _ in reducer.arenas]  # the closing backward is counted from scratch
+                return False
+        return _NoSync()
+
+    def _launch(self, bi, from_hook=False):
         a = self.arenas[bi]
-        a.adopt()
+        # from inside backward a parameter without a gradient keeps `.grad` None (see the class docstring)
+        a.adopt(assign_missing=not from_hook)
+        a.in_flight = True
         self.work[bi] = dist.all_reduce(a.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.launch_order.append(bi)
 
     def wait(self):
-        if self.world == 1:
+        if not self.active:
             return
         for bi in range(len(self.arenas)):
             if self.work[bi] is None:
                 self._launch(bi)
         for bi, a in enumerate(self.arenas):
             self.work[bi].wait()
-            a.flat.mul_(1.0 / self.world)
+        if self.error is not None:
+            msg, self.error = self.error, None
+            for bi, a in enumerate(self.arenas):
+                self.work[bi], self.fired[bi], self.late[bi], a.in_flight = None, set(), {}, False
+            self.launch_order = []
+            raise RuntimeError("GradReducer: " + msg)
+        for bi, a in enumerate(self.arenas):
+            if self.late[bi]:
+                # second round: the late gradients move into their (zero) slices and those slices are reduced
+                for p in self.late[bi].values():
+                    v = a.view(a.index[id(p)])
+                    v.copy_(p.grad)
+                    p.grad = v
+                    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+                    self.late_rounds += 1
+                self.fired[bi] |= set(self.late[bi])
+                self.late[bi] = {}
+            a.in_flight = False
+            a.adopt()  # parameters without a gradient: `.grad` = their (zero) slice, the documented post-condition
+            if self.world > 1:
+                a.flat.mul_(1.0 / self.world)
             a.touched = False
             self.expected[bi] = self.fired[bi]
             self.fired[bi] = set()

@@ -85,6 +85,71 @@ def main():
         if step > 0:  # from the second step on HeadNeRFNet's bucket goes out from inside backward, ahead of the other one
             assert reducer.last_launch_order[0] == 0 and reducer.hook_launches >= step, (reducer.last_launch_order, reducer.hook_launches)
     worst = max(worst, worst2)
+
+    # ---- gradient accumulation: two backward passes per step.  Under no_sync() the first launches nothing; the closing
+    # backward is counted from scratch and the step's average is that of the SUM of both passes
+    def one_backward(scale):
+        a = bucket.flat.sum() * 0.0 + 1.0
+        (sum((p * base[n]).sum() for n, p in used) * a * float(rank + 1) * scale + bucket.flat.sum() * float(rank + 1) * scale).backward()
+
+    for p in params:
+        p.grad = None
+    with reducer.no_sync():
+        one_backward(1.0)
+    one_backward(2.0)
+    reducer.wait()
+    worst3 = 0.0
+    for n, p in used:
+        worst3 = max(worst3, float((p.grad - base[n] * mean * 3.0).abs().max()))
+    worst3 = max(worst3, float((bucket.flat.grad - mean * 3.0).abs().max()))
+    worst = max(worst, worst3)
+    # ... and WITHOUT no_sync() the second backward accumulates into slices that are being reduced: wait() must refuse
+    for p in params:
+        p.grad = None
+    one_backward(1.0)       # bucket 0 goes out from inside this backward (steady state)
+    one_backward(2.0)       # accumulates into the slices in flight
+    try:
+        reducer.wait()
+        raised = False
+    except RuntimeError as e:
+        raised = "no_sync" in str(e)
+    assert raised, "a second backward() before wait() must raise, not average half a gradient"
+    # the reducer is usable again afterwards
+    for p in params:
+        p.grad = None
+    one_backward(1.0)
+    reducer.wait()
+    for n, p in used:
+        worst = max(worst, float((p.grad - base[n] * mean).abs().max()))
+
+    # ---- a GROWING parameter set: the fine network receives gradients for the first time, and (its terms are created first
+    # in the forward, so autograd reaches them last) AFTER bucket 0 went out from the hook.  Its slices went out as zeros; the
+    # late gradients are reduced in a second round.
+    late_before = reducer.late_rounds
+    for p in params:
+        p.grad = None
+    fine = [(n, p) for n, p in net.named_parameters() if n.startswith("fine_fg_CD_predictor.")]
+    late_term = sum((p * base[n]).sum() for n, p in fine) * float(rank + 1)
+    a = bucket.flat.sum() * 0.0 + 1.0
+    (sum((p * base[n]).sum() for n, p in used) * a * float(rank + 1) + bucket.flat.sum() * float(rank + 1) + late_term).backward()
+    reducer.wait()
+    assert reducer.late_rounds > late_before, "the late path was not exercised (the fine network fired before the launch)"
+    worst4 = 0.0
+    for n, p in net.named_parameters():
+        worst4 = max(worst4, float((p.grad - base[n] * mean).abs().max()))
+        assert arena.is_view(arena.index[id(p)], p.grad)
+    worst = max(worst, worst4)
+    # next step: the grown set is the expected one, nothing is late
+    late_before = reducer.late_rounds
+    for p in params:
+        p.grad = None
+    late_term = sum((p * base[n]).sum() for n, p in fine) * float(rank + 1)
+    a = bucket.flat.sum() * 0.0 + 1.0
+    (sum((p * base[n]).sum() for n, p in used) * a * float(rank + 1) + bucket.flat.sum() * float(rank + 1) + late_term).backward()
+    reducer.wait()
+    assert reducer.late_rounds == late_before
+    for n, p in net.named_parameters():
+        worst = max(worst, float((p.grad - base[n] * mean).abs().max()))
     reducer.close()
 
     csum = float(sum(p.detach().double().sum() for p in net.parameters()) + sum(b.double().sum() for b in net.buffers()))

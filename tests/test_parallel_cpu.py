@@ -142,3 +142,48 @@ def test_bench_gpus_flag_is_not_dead(tmp_path):
     env["WORLD_SIZE"], env["RANK"], env["LOCAL_RANK"] = "4", "0", "0"
     r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_gradient_arena_survives_a_backward_that_raises():
+    """FlatGrads hands slices out once per backward pass and learns that a pass is over from an engine callback -- which the
+    engine never runs when backward raises (an out-of-memory batch a training loop skips).  The next pass must still get
+    zeroed arena slices for every parameter, and gradients equal to what fresh buffers give."""
+    from n3dt import parallel
+    torch.manual_seed(0)
+    w1 = torch.nn.Parameter(torch.randn(5))
+    w2 = torch.nn.Parameter(torch.randn(7))
+    arena = parallel.FlatGrads([w1, w2])
+
+    class Accum(torch.autograd.Function):
+        """Stands for a backward kernel: accumulates into the slices the arena hands out and returns them."""
+
+        @staticmethod
+        def forward(ctx, x, w, boom):
+            ctx.w, ctx.boom = w, boom
+            return x * w.detach().sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            if ctx.boom:
+                raise RuntimeError("out of memory (simulated)")
+            views = arena.hand_out([ctx.w])
+            assert views is not None, "the arena must be usable in this pass"
+            views[0] += g.sum()  # a kernel would `+=` into a zeroed slice
+            return g * ctx.w.detach().sum(), views[0], None
+
+    x = torch.ones(3, requires_grad=True)
+    # pass 1: w1's slice is handed out, then the graph raises -> the final callback never runs
+    with pytest.raises(RuntimeError, match="simulated"):
+        (Accum.apply(Accum.apply(x, w2, True), w1, False)).sum().backward()
+    assert arena._in_pass, "precondition of this test: the raising pass left the flag set"
+    w1.grad = w2.grad = None
+    # leave something stale in the arena (as last step's averaged gradients would be)
+    arena.flat.fill_(123.0)
+    # pass 2: both parameters must get zeroed slices of the arena again
+    (Accum.apply(Accum.apply(x, w2, False), w1, False)).sum().backward()
+    assert arena.is_view(0, w1.grad) and arena.is_view(1, w2.grad)
+    g1, g2 = w1.grad.clone(), w2.grad.clone()
+    # (the stale 123.0 is gone, nothing was accumulated onto it): outer parameter sum(g) = 3, inner one 3 * sum(w1)
+    assert torch.allclose(g1, torch.full_like(g1, 3.0))
+    assert torch.allclose(g2, torch.full_like(g2, 3.0 * float(w1.detach().sum())))
+    assert not arena._in_pass

@@ -11,6 +11,9 @@ the drawn rays has an almost vanishing gradient into the MLP (|d density weight|
 does one with fewer than 512 sample points in all: there
 the two paths differ by rounding noise on a cancelled sum (cosine down to 0.87, tools/fuzz_train_probe.py); those are reported
 and held to cosine >= 0.85.  bf16 operand rounding through ten chained layers keeps the descent direction, not every entry.
+THE CLASSIFICATION RULE IS FROZEN (round 4): a case is in the loose band iff  max|d density_module.weight| (fp32 path) < 1e-2
+OR  B * fs^2 * ns < 512;  nothing else enters it, and a run fails when more than 40 % of its draws land there.  A case outside
+the rule that misses the tight band is a finding to be explained by the kernels, not by another clause here.
 Camera gradients are REPORTED, not asserted: their 2^k-weighted cancellation over a few hundred samples makes the bf16 path's
 d R / d T a direction of varying quality on tiny geometries (cosine 0.75 - 1.0 seen), which is why train_precision="fp32" is the
 mode for fitting cameras.
@@ -23,6 +26,9 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "nerf-3dtalker-code_amd"))
+
+
+LOOSE_MAX = 0.40  # share of the draws the loose band may take (seen over seeds 1, 5, 7, 9, 11: 20 - 33 %)
 
 
 def variant_kw(variant):
@@ -63,7 +69,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
-    bad = 0
+    bad = loose = 0
     worst = {"max": 0.0, "cos": 1.0, "cam_cos": 1.0}
     for case in range(cases):
         fs = int(rng.choice([4, 6, 8, 10, 12, 16, 20]))
@@ -87,6 +93,7 @@ def main():
         # ... and so is a case with only a few hundred sample points in all (4 x 4 rays x 3 samples x 3 frames = 144: cosine 0.977,
         # seed 11): the rounding noise of the bf16 chain averages out over the points a gradient is summed over
         vanishing = vanishing or B * fs * fs * ns < 512
+        loose += int(vanishing)
         if float((img32 - img16).abs().max()) > 4e-3:
             msg.append("image %.2e" % float((img32 - img16).abs().max()))
         for k in g32:
@@ -120,6 +127,11 @@ def main():
         sys.stdout.flush()
     print("%d / %d cases failed; worst non-camera tensor: max error %.3f of scale, cosine %.5f; worst camera-gradient cosine %.3f" %
           (bad, cases, worst["max"], worst["cos"], worst["cam_cos"]))
+    # the loose band is an exception, not a refuge: the run fails when more than LOOSE_MAX of the draws land in it
+    print("%d / %d cases in the loose band (limit %.0f %%)" % (loose, cases, 100 * LOOSE_MAX))
+    if loose > LOOSE_MAX * cases:
+        print("FAIL: too many cases classified into the loose band")
+        return 1
     return 1 if bad else 0
 
 
