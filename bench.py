@@ -209,25 +209,49 @@ def run_render(ctx, config, precision, batch, rays, steps, warmup, prof=True, ke
     }
 
 
-def run_train(ctx, config, train_precision, batch, steps, warmup, audio2style_bucket=True):
-    """BASELINE config 3: one reference-shaped train step = forward("train") -> 3 MSE terms -> backward -> Adam x 2
-    (talker_trainer.py:1002-1067), plus -- when world > 1 -- ONE flat-buffer all-reduce of the gradients of
-    HeadNeRFNet and of a 21.5 M-parameter stand-in for the co-trained Audio2style module (talker_trainer.py:428-473,665)."""
+def lib_sha16():
+    """sha256[:16] of the libn3dt.so this process runs (what profiles/traffic.json's `_lib_sha16` is compared with)."""
+    import hashlib
+    path = os.path.join(REPO, "nerf-3dtalker-code_amd", "lib", "libn3dt.so")
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def load_traffic():
+    tpath = os.path.join(REPO, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return {}
+    with open(tpath) as f:
+        return json.load(f)
+
+
+def run_train(ctx, config, train_precision, batch, steps, warmup, audio2style_bucket=True, graph=False):
+    """BASELINE config 3 / 4: one reference-shaped train step = forward("train") -> 3 MSE terms -> backward -> Adam x 2
+    (talker_trainer.py:1002-1067: HeadNeRFNet's Adam(lr=1e-4) :722-723 and Audio2style's Adam(lr=1e-7, betas=(.5,.999)) :665 over
+    a 21.5 M-parameter stand-in for that co-trained module, at every N), plus -- when world > 1 -- the in-place all-reduce of
+    both gradient buckets.  graph=True: the whole step (forward, loss, backward, both optimizers) is ONE hipGraph replay
+    (n3dt.train.GraphedTrainStep)."""
+    import numpy as np
     import torch
-    from n3dt import parallel
+    from n3dt import parallel, _lib
     from n3dt.train import fused_data_losses as data_losses, disk_mask
     opt, sd, net, d = build(ctx, config, "fp32", batch, "R", train_precision=train_precision)
     fs, ns, pred = GEOMETRY[config]
+    capt = dict(capturable=True) if graph else {}
     # the reference's Adam (talker_trainer.py:722-723), as PyTorch's single-kernel ("fused") implementation of the same update
-    optim = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
+    optim = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True, **capt)
     bucket = optim_a2s = None
-    if audio2style_bucket and ctx.world > 1:
+    if audio2style_bucket:
         bucket = parallel.FlatBucket().to(ctx.dev)
-        optim_a2s = torch.optim.Adam(bucket.parameters(), lr=1e-7, betas=(0.5, 0.999))
+        optim_a2s = torch.optim.Adam(bucket.parameters(), lr=1e-7, betas=(0.5, 0.999), fused=True, **capt)
     gt = torch.full((batch, 3, pred, pred), 0.5, device=ctx.dev)
     mask = disk_mask(batch, pred).to(ctx.dev)
     reducer = None
     if ctx.world > 1:
+        assert not graph, "the graphed step is a one-GPU form (a collective inside a captured backward is not rehearsable here)"
         parallel.broadcast_parameters(net)
         # two buckets, reduced in place (no cat, no copy-back): HeadNeRFNet's gradient arena goes out from inside backward as soon
         # as its last gradient is in, the co-trained module's bucket after it; both are joined before the optimizer steps
@@ -248,23 +272,61 @@ def run_train(ctx, config, train_precision, batch, steps, warmup, audio2style_bu
         if optim_a2s is not None:
             optim_a2s.step()
 
+    if graph:
+        from n3dt.train import GraphedTrainStep
+        step = GraphedTrainStep(step, warmup=3)
+
     for _ in range(warmup):
         step()
     ctx.barrier()
+    n_span = 3 * steps if (train_precision == "bf16" and not graph) else 0
+    _lib.prof_enable(n_span)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     t_enqueued = time.perf_counter() - t0  # host time to ENQUEUE the steps (no synchronisation inside the loop)
     ctx.barrier()
     elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    stage_ms = None
+    if n_span:
+        ms = (ctypes.c_float * n_span)()
+        n_rec = ctypes.c_int(0)
+        _lib.lib().n3dt_prof_collect(ms, n_span, ctypes.byref(n_rec))
+        if n_rec.value == n_span:
+            a = np.asarray(list(ms), dtype=np.float64).reshape(steps, 3)
+            stage_ms = [float(v) for v in a.mean(axis=0)]   # training forward kernel, dX chain, weight-gradient stage
+    _lib.prof_enable(0)
+    points = batch * fs * fs * ns
+    ms_per_step = 1e3 * elapsed / steps
+    roof = None
+    if train_precision == "bf16":
+        flop = 3.0 * FLOP_PER_POINT * points   # forward + input gradients + weight gradients of the MLP query, algorithmic
+        roof = {"kernel": "nerf_fwd_x16_train_kernel + nerf_bwd_x16_kernel + dw_x16_* (the volumetric stage of one step)",
+                "bound": "mfma", "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "flop_per_point_algorithmic": 3 * FLOP_PER_POINT,
+                "points_per_step": points, "step_achieved": flop / (ms_per_step * 1e-3) / 1e12,
+                "step_frac": flop / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"]}
+        if stage_ms is not None:
+            k = sum(stage_ms)
+            roof.update({"achieved": flop / (k * 1e-3) / 1e12, "frac": flop / (k * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
+                         "avg_launch_ms": k, "fwd_kernel_ms": stage_ms[0], "dx_chain_ms": stage_ms[1], "dw_stage_ms": stage_ms[2]})
+        else:
+            roof.update({"achieved": roof["step_achieved"], "frac": roof["step_frac"], "avg_launch_ms": None})
+        tr = load_traffic()
+        key = "train_%s_bf16_b%d" % (config, batch)
+        roof["traffic"] = tr.get(key)
+        roof["traffic_lib_sha16"] = tr.get("_train_lib_sha16") if tr.get(key) is not None else None
+        roof["lib_sha16"] = lib_sha16()
     return {
-        "elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "frames_per_s": ctx.world * batch * steps / elapsed,
-        "host_enqueue_ms_per_step": 1e3 * t_enqueued / steps,
+        "elapsed": elapsed, "ms_per_step": ms_per_step, "frames_per_s": ctx.world * batch * steps / elapsed,
+        "host_enqueue_ms_per_step": 1e3 * t_enqueued / steps, "roofline": roof, "graph": bool(graph),
+        "optimizers": 2 if optim_a2s is not None else 1,
         "allreduce_bytes_per_step": reducer.bytes_per_step() if reducer is not None else 0,
         "allreduce_buckets": [a.numel * 4 for a in reducer.arenas] if reducer is not None else [],
         "allreduce_launched_inside_backward": reducer.hook_launches if reducer is not None else 0,
-        "workload": "%s: %d heads/GPU/step, %dx%d rays x %d samples -> %dx%d, 3 MSE terms, Adam" % (
-            "cfg3" if config == "cfg2" else config + "-train", batch, fs, fs, ns, pred, pred),
+        "workload": "%s: %d heads/GPU/step, %dx%d rays x %d samples -> %dx%d, 3 MSE terms, Adam x %d%s" % (
+            "cfg3" if config == "cfg2" else config + "-train", batch, fs, fs, ns, pred, pred, 2 if optim_a2s is not None else 1,
+            ", one hipGraph replay per step" if graph else ""),
     }
 
 
@@ -428,6 +490,10 @@ def extras(ctx):
                  "steps": steps, "warmup": warmup}
             if "host_enqueue_ms_per_step" in r:
                 e["host_enqueue_ms_per_step"] = r["host_enqueue_ms_per_step"]
+                e["optimizers"], e["graph"] = r.get("optimizers"), r.get("graph")
+                if r.get("roofline"):
+                    e["roofline"] = {k: r["roofline"].get(k) for k in ("achieved", "frac", "step_frac", "avg_launch_ms", "fwd_kernel_ms",
+                                                                      "dx_chain_ms", "dw_stage_ms", "traffic")}
             if "frac" in r:
                 e["fused_mlp_kernel_ms"] = r["kern_ms"]
                 e["roofline_frac"] = r["frac"]
@@ -447,7 +513,9 @@ def extras(ctx):
     rec("cfg3_train_bf16_b2", "fused bf16 training path", lambda k, w: run_train(ctx, "cfg2", "bf16", 2, k, w), 30, 6)
     rec("cfg3_train_fp32_b2", "exact fp32 training path", lambda k, w: run_train(ctx, "cfg2", "fp32", 2, k, w), 4, 2)
     rec("cfg4_bf16_b4", "bf16", lambda k, w: run_render(ctx, "cfg4", "bf16", 4, "R", k, w, prof=False), 20, 5)
-    rec("cfg4_train_bf16_b2", "fused bf16 training path", lambda k, w: run_train(ctx, "cfg4", "bf16", 2, k, w), 30, 6)
+    rec("cfg4_train_bf16_b4", "fused bf16 training path, 4 heads per GPU (config 4)", lambda k, w: run_train(ctx, "cfg4", "bf16", 4, k, w), 30, 6)
+    rec("cfg4_train_bf16_b4_graph", "the same step as ONE hipGraph replay", lambda k, w: run_train(ctx, "cfg4", "bf16", 4, k, w, graph=True), 30, 6)
+    rec("cfg3_train_bf16_b2_graph", "config 3's step as ONE hipGraph replay", lambda k, w: run_train(ctx, "cfg2", "bf16", 2, k, w, graph=True), 30, 6)
     rec("cfg4_fit_bf16_b1", "single-image fitting iteration (256^2 geometry, as model_Reso32), fused bf16 training path",
         lambda k, w: run_fit(ctx, "cfg4", "bf16", k, w), 10, 3)
     rec("cfg4_fit_fp32_b1", "single-image fitting iteration, exact fp32 training path (the mode for entry-wise camera gradients)",
@@ -464,7 +532,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default: 16 rendering cfg2, 2 training it, 4 for cfg4 / cfg5)")
+    ap.add_argument("--graph", action="store_true", help="--mode train: the whole step as one hipGraph replay (N = 1)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "bf16x3"])
     ap.add_argument("--rays", default="R", choices=["R", "N"],
                     help="R: rays = featmap_size^2 (reference-faithful); N: 512^2 rays, feature stage only")
@@ -488,8 +557,9 @@ def main():
     default_workload = args.config == "cfg2" and args.mode == "render" and args.rays == "R" and args.precision == "bf16"
     if args.config != "cfg2":
         args.no_cpu_baseline = True  # the reported CPU baseline is the headline workload's
-        if args.batch == 16:
-            args.batch = 4
+    if args.batch is None:
+        # frames per GPU per step: the headline renders 16; config 3 trains 2 (talker_trainer.py batch_size=2); configs 4 / 5: 4 per GPU
+        args.batch = (2 if args.config == "cfg2" else 4) if args.mode == "train" else (16 if args.config == "cfg2" else 4)
 
     ctx = Ctx(args)
     seen = ctx.ranks_seen()
@@ -508,8 +578,8 @@ def main():
         return
     if args.mode == "train":
         tp = "bf16" if args.precision == "bf16" else "fp32"
-        B = min(args.batch, 2)
-        r = run_train(ctx, args.config, tp, B, args.steps, args.warmup)
+        B = args.batch   # config 3: 2 heads per step, config 4: 4 per GPU (BASELINE.json), unless --batch says otherwise
+        r = run_train(ctx, args.config, tp, B, args.steps, args.warmup, graph=args.graph)
         if ctx.rank == 0:
             fs, ns, pred = GEOMETRY[args.config]
             print(json.dumps({
@@ -517,10 +587,12 @@ def main():
                 "value": r["frames_per_s"], "unit": "frames/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": tp, "data": "synthetic",
+                "roofline": r["roofline"],
                 "config": {"workload": r["workload"],
                            "parallelism": "frames sharded over %d rank(s); gradients averaged in place in two flat buckets per step "
                                           "(HeadNeRFNet's arena, launched from inside backward; then a 21.5 M-parameter Audio2style "
                                           "stand-in)" % ctx.world,
+                           "optimizers": r["optimizers"], "graph_replay": r["graph"],
                            "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"],
                            "allreduce_bytes_per_step": r["allreduce_bytes_per_step"], "allreduce_buckets": r["allreduce_buckets"],
                            "allreduce_launched_inside_backward": r["allreduce_launched_inside_backward"],
@@ -533,13 +605,11 @@ def main():
     res = None
     if ctx.rank == 0:
         fs, ns, pred = GEOMETRY[args.config]
-        traffic, traffic_src = None, None
-        tpath = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get("%s_%s_b%d" % (args.rays, args.precision, args.batch))
-            if traffic is not None:
-                traffic_src = "profiles/traffic.json (rocprofv3 PMC passes of this command; not re-measured in this run)"
+        tr = load_traffic()
+        traffic = tr.get("%s_%s_b%d" % (args.rays, args.precision, args.batch))
+        traffic_src = tr.get("_source") if traffic is not None else None
+        traffic_sha = tr.get("_lib_sha16") if traffic is not None else None
+        this_sha = lib_sha16()
         res = {
             "metric": "rendered frames/sec @%d^2 x %d samples/ray" % (pred, ns),
             "value": r["frames_per_s"],
@@ -563,6 +633,8 @@ def main():
                 "kernel": {"fp32": "nerf_fwd_f32_kernel", "bf16x3": "nerf_fwd_x16s_kernel"}.get(args.precision, "nerf_fwd_x16_kernel"),
                 "bound": "mfma", "achieved": r["achieved"], "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s", "frac": r["frac"],
                 "traffic": traffic, "traffic_source": traffic_src,
+                # the counters are not re-measured in this run: which build they were taken on, and whether it is the one running
+                "traffic_lib_sha16": traffic_sha, "lib_sha16": this_sha, "traffic_is_this_build": bool(traffic_sha and traffic_sha == this_sha),
                 "avg_launch_ms": r["kern_ms"], "points_per_launch": r["points"],
                 "flop_per_point_algorithmic": FLOP_PER_POINT,
                 "executed_tflops": r["executed_tflops"],
@@ -588,6 +660,46 @@ def main():
                                        "rgb_linf_seed0": res.get("parity_check", {}).get("bf16x3"),
                                        "rgb_linf_contrast": res.get("parity_check", {}).get("contrast", {}).get("bf16x3")}
     if ctx.rank == 0:
+        # The driver's record keeps `config`, `roofline`, `cpu_baseline` (scalars) and the last 2 000 characters of the line: the
+        # figures a reader needs to check parity, the sustained clock and the training steps go into `config` as flat scalars
+        # and, once more, into `summary`, the LAST key of the line.
+        summ = {}
+        pc = res.get("parity_check")
+        if pc:
+            for w in ("seed0", "contrast", "trained"):
+                src = pc if w == "seed0" else pc.get(w)
+                if isinstance(src, dict):
+                    for prec in ("bf16", "fp16", "bf16x3", "fp32"):
+                        if isinstance(src.get(prec), float):
+                            summ["parity_%s_%s" % (prec, w)] = float("%.3g" % src[prec])
+            summ["parity_ok"] = pc["ok"]
+            if isinstance(pc.get("trained"), dict):
+                summ["trained_alpha_saturated_ray_share"] = pc["trained"].get("alpha_saturated_ray_share")
+        su = res.get("sustained")
+        if su:
+            summ.update({"sustained_ms_per_step": round(su["ms_per_step"], 4), "sustained_kernel_ms": round(su["fused_mlp_kernel_ms_mean"], 4),
+                         "sustained_frac": round(su["roofline_frac"], 4), "sustained_seconds": round(su["seconds"], 2)})
+        pg = res.get("parity_grade")
+        if pg:
+            summ.update({"parity_grade_bf16x3_frames_per_s": round(pg["frames_per_s"], 1), "parity_grade_frac": round(pg["roofline_frac"], 4)})
+        ex = res.get("extra", {})
+        for name, short in (("cfg3_train_bf16_b2", "cfg3_train"), ("cfg3_train_bf16_b2_graph", "cfg3_train_graph"),
+                            ("cfg4_train_bf16_b4", "cfg4_train_b4"), ("cfg4_train_bf16_b4_graph", "cfg4_train_b4_graph")):
+            e = ex.get(name, {})
+            if "ms_per_step" in e:
+                summ[short + "_ms"] = round(e["ms_per_step"], 4)
+                summ[short + "_host_enqueue_ms"] = round(e.get("host_enqueue_ms_per_step", float("nan")), 4)
+                rf = e.get("roofline") or {}
+                if rf.get("step_frac") is not None:
+                    summ[short + "_step_frac_of_bf16_peak"] = round(rf["step_frac"], 4)
+                if rf.get("avg_launch_ms") is not None:
+                    summ[short + "_volumetric_kernels_ms"] = round(rf["avg_launch_ms"], 4)
+                    summ[short + "_volumetric_frac"] = round(rf["frac"], 4)
+            elif "error" in e:
+                summ[short + "_error"] = e["error"][:100]
+        if summ:
+            res["config"].update(summ)
+            res["summary"] = summ
         print(json.dumps(res), flush=True)
     ctx.close()
     if not parity_ok:

@@ -156,6 +156,23 @@ extern "C" int n3dt_prof_enable(int max_records) {
     return N3DT_OK;
 }
 
+// A measured span: begin records an event on `s` and returns its slot (or -1: hook off / record list full), end records the
+// closing event.  Used by n3dt_render_fwd (the fused MLP kernel) and by the fused training path (forward kernel, dX chain,
+// weight-gradient stage: three spans per step, in that order) -- internal, not part of the ABI.
+extern "C" int n3dt_prof_span_begin(hipStream_t s) {
+    if (g_prof_cap <= 0) return -1;  // the unlocked read is the hook's documented contract: enabled from one thread, while idle
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (g_prof_n >= g_prof_cap) return -1;
+    const int slot = g_prof_n++;
+    (void)hipEventRecord(g_prof_ev[2 * slot], s);
+    return slot;
+}
+extern "C" void n3dt_prof_span_end(int slot, hipStream_t s) {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (slot < g_prof_cap) (void)hipEventRecord(g_prof_ev[2 * slot + 1], s);
+}
+
 extern "C" int n3dt_prof_collect(float* ms_out, int capacity, int* n_out) {
     if (!ms_out || !n_out) return fail(N3DT_EINVAL, "n3dt_prof_collect: NULL argument");
     std::lock_guard<std::mutex> lock(g_prof_mu);
@@ -214,10 +231,7 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
     float* part = (float*)(ws + c.part);
     float* wlocal = (float*)(ws + c.wlocal);
     n3dt_launch_fold(g, p, shape, appea, audio, fold, precision != N3DT_F32, s);
-    std::unique_lock<std::mutex> prof_lock(g_prof_mu, std::defer_lock);
-    if (g_prof_cap > 0) prof_lock.lock();  // the unlocked read is the hook's documented contract: enabled from one thread, while idle
-    const bool prof = prof_lock.owns_lock() && g_prof_n < g_prof_cap;
-    if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_n], s);
+    const int span = n3dt_prof_span_begin(s);
     if (precision == N3DT_F32)
         n3dt_launch_nerf_fwd_f32(g, p, packed_mlp, fold, xy, R, T, Kinv, t_rand, part, weight ? wlocal : nullptr, s);
     else if (precision == N3DT_BF16X3)
@@ -227,11 +241,7 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
                                   Kinv, t_rand, part, weight ? wlocal : nullptr, s);
     else
         n3dt_launch_nerf_fwd_x16(g, precision, packed_mlp, fold, xy, R, T, Kinv, t_rand, part, weight ? wlocal : nullptr, s);
-    if (prof) {
-        (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], s);
-        ++g_prof_n;
-    }
-    if (prof_lock.owns_lock()) prof_lock.unlock();
+    n3dt_prof_span_end(span, s);
     const float* tail = (const float*)((const unsigned char*)packed_mlp + n3dt_packed_tail_offset(precision));
     const float* bghwc = bg_featmap;
     if (merge_feat && !g->bg_is_hwc) {  // [C][N_r] parameter -> [N_r][C]

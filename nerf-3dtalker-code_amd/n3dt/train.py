@@ -152,3 +152,36 @@ def train_step(net, optimizer, inputs, gt_rgb, mask, t_rand=None, extra_optimize
         o.step()
     terms["total_loss"] = total
     return pred, terms
+
+
+class GraphedTrainStep:
+    """One whole training step -- forward("train"), loss tail, backward, optimizer step(s) -- recorded ONCE into a hipGraph and
+    replayed with one launch per step.  Every libn3dt entry point only enqueues on the caller's stream and allocates nothing, the
+    autograd Functions allocate through PyTorch's caching allocator (a graph gets its private pool) and HeadNeRFNet's gradient
+    arena is persistent, so the ~100 launches of a step are capturable as they are.  What the caller must provide:
+      * `step_fn()` reads its inputs from tensors whose ADDRESSES do not change (refresh them with `.copy_()` before a
+        replay) and takes no data-dependent Python branch;
+      * optimizers built with `capturable=True` (their step counters then live on the device);
+      * `zero_grad(set_to_none=True)` inside step_fn (the default), so that backward re-adopts the arena slices.
+    Train-mode jitter: the forward's `torch.rand` is registered with the graph (PyTorch's graph-safe Philox offsets), so
+    every replay draws fresh noise.  `warmup` eager steps run first on a side stream (allocator and optimizer state warm).
+    The reference's step is launch-bound at small geometries (config 4: 2.1 of 2.6 ms is host enqueue time); a replay costs
+    the host one launch."""
+
+    def __init__(self, step_fn, warmup=3):
+        self.step_fn = step_fn
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step_fn()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.out = step_fn()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out

@@ -216,7 +216,7 @@ def _grads(opt, sd, B, precision, t_rand, cam=False):
     return out["merge_img"].detach(), g
 
 
-@pytest.mark.parametrize("fs,ns,B", [(16, 40, 1), (16, 96, 3), (32, 64, 2)])
+@pytest.mark.parametrize("fs,ns,B", [(16, 40, 1), (16, 96, 3), (32, 64, 2), (32, 64, 4)])  # the last: config 4's shape, 4 heads per GPU
 def test_fused_bf16_training_path_against_the_fp32_path(fs, ns, B):
     """The fused mixed-precision path (nerf_fwd_x16_train / nerf_bwd_x16 / dw_x16 kernels) against the exact fp32 path on
     the same inputs, including sample counts that leave the last 32-sample block of a ray ragged (40) and three blocks
