@@ -458,11 +458,46 @@ def parity_check(ctx, opt, sd, ref_seed0):
             del net
         out[name] = errs
     torch.cuda.empty_cache()
+    out["trained"] = trained_parity(ctx)
     ok = all(out[w][p] <= PARITY_GATE for w in out for p in ("bf16x3", "fp32"))
     return {"bf16": out["seed0"]["bf16"], "bf16x3": out["seed0"]["bf16x3"], "fp32": out["seed0"]["fp32"],
-            "contrast": out["contrast"], "gate": PARITY_GATE, "gated_modes": ["bf16x3", "fp32"], "ok": ok,
+            "contrast": out["contrast"], "trained": out["trained"], "gate": PARITY_GATE, "gated_modes": ["bf16x3", "fp32"], "ok": ok,
             "what": "RGB L-inf (merge_img and bg_img) of one cfg2-R frame, GPU vs the CPU oracle, seed-0 weights; "
-                    "`contrast` = the same on the sharp-density weights"}
+                    "`contrast` = the same on the hand-scaled sharp-density weights; `trained` = one config-4 frame on a network the "
+                    "build's own fp32 trainer made sharp (n3dt.synthetic.train_sharp_head), four precisions"}
+
+
+def trained_parity(ctx):
+    """a TRAINED network across the inference precisions.  Seed-0 weights at config 4's geometry, trained by the
+    build's own exact-fp32 path against a sharp target until alpha saturates on >= 20 % of the rays (a few seconds), then frame 0
+    rendered in bf16 / fp16 / bf16x3 / fp32 against the CPU oracle on those weights."""
+    import numpy as np
+    import torch
+    from n3dt import HeadNeRFNet, BaseOptions, synthetic as syn
+    from oracle import oracle as orc
+    fs, ns, pred = GEOMETRY["cfg4"]
+    opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": pred, "num_sample_coarse": ns})
+    net, info = syn.train_sharp_head(opt, ctx.dev, steps=400, lr=1e-3, batch=2)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    del net
+    one = syn.frame_inputs(opt, 1)
+    d = {k: (v.to(ctx.dev) if torch.is_tensor(v) else v) for k, v in one.items()}
+    ref = orc.forward(sd, opt, one)
+    errs = {}
+    for prec in ("bf16", "fp16", "bf16x3", "fp32"):
+        n2 = HeadNeRFNet(opt, include_vd=False, hier_sampling=False, precision=prec).to(ctx.dev)
+        n2.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            r = n2("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"],
+                   d["batch_Rmats"], d["batch_Tvecs"], d["batch_inv_inmats"])["coarse_dict"]
+        torch.cuda.synchronize()
+        errs[prec] = max(float(np.abs(r["merge_img"].cpu().numpy() - ref["merge_img"]).max()),
+                         float(np.abs(r["bg_img"].cpu().numpy() - ref["bg_img"]).max()))
+        del n2
+    torch.cuda.empty_cache()
+    errs.update({k: info[k] for k in ("steps", "lr", "alpha_saturated_ray_share", "one_sample_rays_share", "transparent_ray_share",
+                                      "weight_max", "fg_feat_abs_max", "loss_first", "loss_last")})
+    return errs
 
 
 def sustained(ctx, args, ms_per_step):
@@ -675,6 +710,8 @@ def main():
             summ["parity_ok"] = pc["ok"]
             if isinstance(pc.get("trained"), dict):
                 summ["trained_alpha_saturated_ray_share"] = pc["trained"].get("alpha_saturated_ray_share")
+                summ["trained_one_sample_rays_share"] = pc["trained"].get("one_sample_rays_share")
+                summ["trained_steps"] = pc["trained"].get("steps")
         su = res.get("sustained")
         if su:
             summ.update({"sustained_ms_per_step": round(su["ms_per_step"], 4), "sustained_kernel_ms": round(su["fused_mlp_kernel_ms_mean"], 4),

@@ -244,3 +244,77 @@ def frame_inputs(opt, batch, n_side=None, yaw_range=0.3, include_gaze=False, eye
         "batch_Tvecs": T,
         "batch_inv_inmats": inv_intrinsics(grid, batch),
     }
+
+
+def sharp_target(batch, size, radius=0.35, seed=4321):
+    """Training target of train_sharp_head: inside a disk a smooth seeded colour pattern in [0.1, 0.9], outside white (the
+    reference's white background, Utils/HeadNeRFLossUtils.py:77-80).  Returns (gt [B,3,P,P], mask [B,1,P,P])."""
+    gen = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(size, dtype=torch.float32), torch.arange(size, dtype=torch.float32), indexing="ij")
+    r2 = (xx - size / 2.0) ** 2 + (yy - size / 2.0) ** 2
+    m = (r2 <= (radius * size) ** 2).float()
+    gts = []
+    for _ in range(batch):
+        ch = []
+        for _c in range(3):
+            fx, fy, ph = (torch.rand(3, generator=gen) * torch.tensor([3.0, 3.0, 6.28])).tolist()
+            ch.append(0.5 + 0.4 * torch.sin(6.2832 * (fx * xx + fy * yy) / size + ph))
+        g = torch.stack(ch)
+        gts.append(g * m + (1.0 - m))
+    return torch.stack(gts), m.view(1, 1, size, size).repeat(batch, 1, 1, 1)
+
+
+def train_sharp_head(opt, dev, steps=400, lr=1e-3, batch=2, train_precision="fp32", seed=0, want_share=0.2, check_every=25,
+                     log_every=0, log=None):
+    """A head made sharp by the build's OWN trainer (the released checkpoints are absent, so what a trained network
+    looks like to the 16-bit arithmetic is answered by training one): seed-`seed` weights, `steps` Adam steps (at most) of the
+    differentiable path (`train_precision`, exact fp32 by default) on `batch` synthetic frames against sharp_target() with the
+    reference's three data terms, stopping once alpha has saturated on `want_share` of the rays in both senses: the ray is opaque
+    (bg_alpha < 0.01) AND one sample carries it (compositing weight > 0.9: a hard surface, what stresses 16-bit arithmetic).
+    Measured at config 4's geometry, lr 1e-3, B = 2: 150 - 200 steps (3 - 4 s), the loss falls 180-fold, 25 % of the rays end on
+    one sample, every ray is opaque.  Returns (net, info); info carries the alpha statistics."""
+    from . import HeadNeRFNet
+    from .train import fused_data_losses
+    net = HeadNeRFNet(opt, include_vd=False, hier_sampling=False, precision="fp32", train_precision=train_precision).to(dev)
+    net.load_state_dict(make_state_dict(opt, seed=seed, bg_noise=0.1), strict=True)
+    d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in frame_inputs(opt, batch).items()}
+    gt, mask = sharp_target(batch, opt.pred_img_size)
+    gt, mask = gt.to(dev), mask.to(dev)
+    optim = torch.optim.Adam(net.parameters(), lr=lr)
+    args = (d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"], d["batch_Tvecs"],
+            d["batch_inv_inmats"])
+
+    def stats():
+        with torch.no_grad():
+            o = net.render_features(d["batch_xy"], d["audiostyle"], d["shape_code"], d["appea_code"], d["batch_Rmats"], d["batch_Tvecs"],
+                                    d["batch_inv_inmats"], want_merge=False, want_weight=True, precision="fp32")
+        ba = o["bg_alpha"].float()
+        w = o["weight"].float()
+        return {"alpha_saturated_ray_share": float((ba < 0.01).float().mean()), "transparent_ray_share": float((ba > 0.5).float().mean()),
+                "one_sample_rays_share": float((w.max(dim=-1).values > 0.9).float().mean()),  # one sample carries the ray: a hard surface
+                "weight_max": float(w.max()), "fg_feat_abs_max": float(o["fg_feat"].abs().max())}
+
+    loss0 = lossv = None
+    done = 0
+    st = stats()
+    for it in range(steps):
+        out = net("train", *args)
+        t = fused_data_losses(out["coarse_dict"], gt, mask)
+        optim.zero_grad()
+        t["total_loss"].backward()
+        optim.step()
+        done = it + 1
+        if it == 0:
+            loss0 = float(t["total_loss"].detach())
+        if done % check_every == 0 or done == steps:
+            st = stats()
+            lossv = float(t["total_loss"].detach())
+            if log is not None and log_every and done % log_every == 0:
+                log("step %4d  loss %.5f  %s" % (done, lossv, st))
+            if st["alpha_saturated_ray_share"] >= want_share and st["one_sample_rays_share"] >= want_share:
+                break
+    net.zero_grad(set_to_none=True)
+    info = dict(st)
+    info.update({"steps": done, "lr": lr, "batch": batch, "train_precision": train_precision, "loss_first": loss0, "loss_last": lossv,
+                 "target": "disk of a seeded colour pattern on white, bg + head + nonhead MSE terms"})
+    return net, info
