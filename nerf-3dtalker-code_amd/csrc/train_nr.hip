@@ -1149,8 +1149,15 @@ static void nr_bwd16(const N3dtGeom* g, int nb, const N3dtRenderParams* p, const
 }
 
 static bool nr16_enabled(const N3dtGeom* g) {
-    const char* e = getenv("N3DT_NR_TRAIN_FUSED");  // 0: the layered bf16 path (A/B)
-    return (!e || atoi(e) != 0) && nr16_supported(g);
+    // N3DT_NR_TRAIN_FUSED=0: the layered bf16 path (A/B).  LATCHED once per process: the two paths lay `saved` and the workspace
+    // out differently (floats against byte offsets of bf16 planes), so a switch that moved between a forward and its backward
+    // would have the backward read `saved` under the wrong layout.  (N3DT_NR_DW_LDS / N3DT_NR_BLUR_MFMA pick kernels inside one
+    // layout and stay per-call switches: the tests compare both forms in one process.)
+    static const bool on = [] {
+        const char* e = getenv("N3DT_NR_TRAIN_FUSED");
+        return !e || atoi(e) != 0;
+    }();
+    return on && nr16_supported(g);
 }
 extern "C" size_t n3dt_nr_train16_saved_bytes(const N3dtGeom* g, int nb) { return nr16_saved_layout(g, nb).total; }
 extern "C" size_t n3dt_nr_train16_ws_bytes(const N3dtGeom* g, int nb) { return nr16_ws_layout(g, nb).total; }

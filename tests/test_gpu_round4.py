@@ -127,3 +127,44 @@ def test_a_network_trained_by_the_builds_own_trainer_across_the_inference_precis
     print("trained-network RGB L-inf vs the oracle:", errs, info)
     assert errs["fp32"] <= 1e-3 and errs["bf16x3"] <= 1e-3, errs
     assert errs["bf16"] <= 0.2 and errs["fp16"] <= 0.2, errs
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_a_non_finite_feature_stays_local_in_the_renderer(precision):
+    """One NaN in the renderer's input map.  In the reference it spreads only as far as the 3x3 blurs and the bilinear
+    upsampling carry it (NetWorks/neural_renderer.py:72-91): a ~25-pixel patch of the 256^2 image.  The 16-bit path evaluates the
+    blur / activation / RGB stage as a matrix product over 32- or 64-pixel tiles (csrc/nr_blur_mfma.inc): every halo slot is
+    multiplied by its stencil weight, 0 included, so a NaN anywhere in a tile's input patch reaches ALL of that tile's output pixels
+    (0 * NaN) -- a documented deviation: the poisoned set is a superset of the reference's, larger by at most a
+    tile per level, and everything outside it is bit-identical to the clean render.  The exact fp32 path poisons exactly the
+    reference's pixels."""
+    from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
+    from oracle import oracle as orc
+    opt = BaseOptions({"featmap_size": 32, "featmap_nc": 256, "pred_img_size": 256, "num_sample_coarse": 8})
+    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
+    net = HeadNeRFNet(opt, False, False, precision=precision).to(dev())
+    net.load_state_dict(sd, strict=True)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 256, 32, 32, generator=gen)
+    xn = x.clone()
+    xn[0, 17, 13, 21] = float("nan")
+    ref = orc.neural_render(sd, xn.numpy(), 3)
+    bad_ref = ~np.isfinite(ref).all(axis=1)[0]          # [256,256] pixels the reference poisons
+    assert 100 < bad_ref.sum() < 2000
+
+    def render(t):
+        hwc = t.permute(0, 2, 3, 1).contiguous().to(dev())
+        with torch.no_grad():
+            return net.neural_render.render_hwc(hwc, precision).cpu().numpy()
+    clean, dirty = render(x), render(xn)
+    bad = ~np.isfinite(dirty).all(axis=1)[0]
+    assert (bad | ~bad_ref).all(), "a pixel the reference poisons came out finite"
+    if precision == "fp32":
+        assert (bad == bad_ref).all()
+    ys, xs = np.nonzero(bad_ref)
+    y0, y1, x0, x1 = ys.min(), ys.max(), xs.min(), xs.max()
+    grow = 56  # a tile edge (8 pixels) per level, scaled by the upsamplings behind that level: 8 * (4 + 2 + 1)
+    allowed = np.zeros_like(bad)
+    allowed[max(0, y0 - grow):y1 + grow + 1, max(0, x0 - grow):x1 + grow + 1] = True
+    assert not (bad & ~allowed).any(), "NaN reached pixels far from the reference's patch: %d" % int((bad & ~allowed).sum())
+    assert np.array_equal(dirty[0][:, ~bad], clean[0][:, ~bad]), "finite pixels changed"

@@ -170,6 +170,17 @@ def test_stream_hazard_scanner_flags_scalar_and_flat_accesses(tmp_path):
         assert (len(found) == 0) == (name == "waited"), (name, found)
 
 
+def _shipped_asm():
+    """build/*.s -- the device assembly the Makefile keeps next to every object.  build/ is git-ignored: a checkout without
+    hipcc has none (conftest builds the library only where a compiler exists), and a gate on the shipped assembly has nothing
+    to look at there -- skip with the reason instead of failing."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "nerf-3dtalker-code_amd", "build", "*.s")))
+    if not files:
+        pytest.skip("no device assembly under nerf-3dtalker-code_amd/build (built artefacts are git-ignored and no hipcc built them here)")
+    return files
+
+
 def test_shipped_stream_kernels_pass_the_hazard_gate():
     """The static gate on the SHIPPED build: the Makefile keeps the device assembly of the very compile that produced the
     objects linked into libn3dt.so (build/<name>.s, same FLAGS); scan() and scan_inflight() must find nothing in any
@@ -179,6 +190,7 @@ def test_shipped_stream_kernels_pass_the_hazard_gate():
     spec = importlib.util.spec_from_file_location("check_smem_hazard", os.path.join(REPO, "tools", "check_smem_hazard.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    _shipped_asm()
     findings, kernels = mod.check_shipped(verbose=False)
     assert not findings, "\n".join(findings)
     # the scan saw the kernels it is there for
@@ -204,9 +216,7 @@ def test_shipped_kernels_stay_within_their_scratch_budget():
         "train_camera_bwd_kernel": None, "train16_camera_bwd_kernel": None,         # per-ray camera adjoints: indexed local arrays
         "nerf_fwd_x16_train_kernel": None,                                            # (as measured in round 2)
     }
-    build = os.path.join(REPO, "nerf-3dtalker-code_amd", "build")
-    files = glob.glob(os.path.join(build, "*.s"))
-    assert files, "no device assembly next to the objects: build with the Makefile"
+    files = _shipped_asm()
     seen = 0
     for path in files:
         kernel = None
@@ -233,9 +243,7 @@ def test_every_stream_rendezvous_waits_for_its_lds_dma():
     the inference kernel's 480 rendezvous, and a parity test failed once in a few hundred GPU runs."""
     import glob
     import re
-    build = os.path.join(REPO, "nerf-3dtalker-code_amd", "build")
-    files = sorted(glob.glob(os.path.join(build, "*.s")))
-    assert files
+    files = _shipped_asm()
     label = re.compile(r"^(_Z\S+|[A-Za-z_][A-Za-z_0-9]*):")
     n_dma_kernels = n_barriers = 0
     for path in files:
@@ -253,6 +261,11 @@ def test_every_stream_rendezvous_waits_for_its_lds_dma():
             m = label.match(line)
             if m:
                 kernel = m.group(1)
+            code = line.split(";")[0]
+            # strict: ANY barrier-like instruction of an LDS-DMA kernel must be the one form this gate understands
+            if kernel in dma and re.search(r"\bs_\w*barrier\w*", code):
+                assert re.search(r"\bs_barrier\b", code), "%s: unrecognised barrier form %r at line %d of %s" % (
+                    kernel, line.strip(), i + 1, os.path.basename(path))
             if kernel in dma and re.search(r"\bs_barrier\b", line) and not line.strip().startswith(";"):
                 n_barriers += 1
                 j, seen, found = i - 1, 0, False

@@ -14,7 +14,7 @@ arrays of intermediate seams / outputs / sampled gradients, and a JSON manifest.
 Weights are NOT stored; they are regenerated from n3dt.synthetic.make_state_dict
 (seeded) and pinned by a checksum.
 
-Usage:  python tools/gen_golden.py [--only NAME ...]
+Usage:  python tools/gen_golden.py [--only NAME ...] [--out DIR]
 """
 import argparse
 import json
@@ -554,7 +554,11 @@ def contrast_state_dict(opt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--out", default=None, help="write the fixtures here instead of tests/golden (tests/test_oracle_golden.py regenerates one into a scratch tree)")
     args = ap.parse_args()
+    if args.out:
+        global OUT
+        OUT = args.out
     torch.manual_seed(0)
     torch.set_num_threads(8)
     HeadNeRFNet, HeadNeRFNetNoAudio = import_reference()
