@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define N3DT_ABI_VERSION 4
+#define N3DT_ABI_VERSION 5
 
 /* arithmetic type of the MLP contraction */
 #define N3DT_F32 0  /* v_mfma_f32_16x16x4_f32, exact fp32: the <=1e-3 RGB parity mode */
@@ -71,6 +71,12 @@ typedef struct N3dtGeom {
     /* 0: `bg_featmap` arguments are the parameter as PyTorch holds it, [C][N_r] (neural_renderer.py:31-46) and the render call
      * transposes it; 1: the caller passes it already ray-major [N_r][C] (e.g. cached per parameter version): no transposition */
     int32_t bg_is_hwc;
+    /* include_vd (ABI 5; reference: NetWorks/HeadNeRFNet.py:56-63,86,141-142).  0: RGB_layer_1's input is [RGB_layer_0 out |
+     * appea_code], as every caller of the reference builds it.  27 (= 3 + 6 * vd_n_freqs): it is [RGB_layer_0 out | Embedder_4(ray
+     * direction) | appea_code].  The direction is constant along a ray, so those 27 columns collapse into a PER-RAY bias of the
+     * layer -- the render calls then take it as `ray_bias` [B, N_r, 192] (n3dt_ray_vd_bias computes it) and `weight[10]` is the
+     * layer WITHOUT its 27 view-direction columns, [192, 384 + appea_dim] contiguous. */
+    int32_t vd_dim;
 } N3dtGeom;
 
 /* The MLP's fp32 parameters as PyTorch owns them: weight[l] is [out_l, in_l] row-major
@@ -134,6 +140,7 @@ int n3dt_mlp_pack(const N3dtGeom* g, int precision, const N3dtMlpParams* p, void
  *   t_rand  [B,N_r,N_s+1] uniform noise for mode=="train" (utils.py:73-78), NULL for "test";
  *           with g->z_planes_given: the sample planes themselves (see N3dtGeom)
  *   bg_featmap  neural_render.bg_featmap [C, N_r] (NCHW parameter), NULL to skip the merge
+ *   ray_bias    [B, N_r, 192] per-ray addend of RGB_layer_1's pre-activation: required iff g->vd_dim > 0 (include_vd), else NULL
  * outputs (any may be NULL, but one of fg_feat / merge_feat must be given):
  *   fg_feat [B,N_r,C]  bg_alpha [B,N_r]  depth [B,N_r]  weight [B,N_r,N_s]
  *   merge_feat [B,N_r,C] = fg_feat + bg_alpha * bg_featmap
@@ -142,9 +149,19 @@ size_t n3dt_render_workspace_bytes(const N3dtGeom* g, int precision);
 int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, const N3dtMlpParams* p,
                     const float* xy, const float* R, const float* T, const float* Kinv,
                     const float* shape, const float* appea, const float* audio, const float* t_rand,
-                    const float* bg_featmap,
+                    const float* bg_featmap, const float* ray_bias,
                     float* fg_feat, float* bg_alpha, float* depth, float* weight, float* merge_feat,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- include_vd: the view-direction columns of RGB_layer_1 as a per-ray bias (ABI 5) -------------------------------
+ * Replaces, for `include_vd=True`: GenSamplePoints' ray direction (NetWorks/utils.py:149-153), `vd_encoder(fg_dirs)`
+ * (HeadNeRFNet.py:141-142: Embedder, 4 frequencies + input = 27 channels, utils.py:20-51), its expand over the samples and the
+ * 27 matching columns of RGB_layer_1 (models.py:80; columns 384 .. 410 of its weight):
+ *   ray_bias[b, r, o] = sum_j w_vd[o * ld_w + j] * Embedder_4(d(b, r))[j],   o < 192, j < 27
+ * w_vd points at RGB_layer_1.weight[0][384] of the FULL parameter ([192, 384 + 27 + appea_dim], ld_w = its row length).
+ * Inference helper; the differentiable path forms the same tensor with autograd on the host (a [B*N_r, 27] x [27, 192] product). */
+int n3dt_ray_vd_bias(const N3dtGeom* g, const float* w_vd, int64_t ld_w, const float* xy, const float* R, const float* Kinv,
+                     float* ray_bias, void* stream);
 
 /* ---- hierarchical (fine) sample planes: SURVEY 8f row 4 ------------------------------------------
  * Replaces FineSample.forward (NetWorks/utils.py:211-263): inverse-CDF resampling of the coarse pass.
@@ -177,6 +194,9 @@ int n3dt_fine_sample(const N3dtGeom* g, int n_fine, const float* weight, const f
 int n3dt_sample_points(const N3dtGeom* g, const float* xy, const float* R, const float* T, const float* Kinv, const float* t_rand,
                        float* pts, float* zvals, float* z_dists, float* ray_d, float* ray_l, void* stream);
 int n3dt_embed(int batch, size_t m, const float* pts, float* pe, void* stream);
+/* the same encoder with n_freqs frequencies (ABI 5): pts [B,3,M] -> pe [B, 3 + 6 n_freqs, M]; n_freqs = 4 is the reference's
+ * vd_encoder (HeadNeRFNet.py:30-31,61), 10 equals n3dt_embed */
+int n3dt_embed_freqs(int batch, size_t m, int n_freqs, const float* pts, float* pe, void* stream);
 size_t n3dt_mlp_points_workspace_bytes(const N3dtGeom* g, size_t m);
 int n3dt_mlp_points(const N3dtGeom* g, size_t m, const N3dtMlpParams* p, const float* audio, const float* embed_vps,
                     const float* embed_vds, float* rgb, float* density, void* workspace, size_t workspace_bytes, void* stream);
@@ -224,6 +244,9 @@ int n3dt_neural_render_fwd_reuse(const N3dtGeom* g, int nb, int precision, const
  *   Camera gradients (the fitting use-case, FittingSingleImage_new.py:826-859): when d_R [B,3,3] and/or d_T [B,3]
  *   are non-NULL they receive dL/d(batch_Rmats), dL/d(batch_Tvecs); xy, R, T, Kinv (and t_rand if the forward
  *   used it) must then be the forward's inputs.  Pass NULL for all seven to skip that work.
+ *   d_ray_bias [B, N_r, 192] (iff g->vd_dim > 0, else NULL) receives dL/d(ray_bias): the per-ray sums of RGB_layer_1's
+ *   pre-activation gradient, from which the caller's autograd forms the gradients of the 27 view-direction columns (and, through
+ *   the ray direction, of the camera rotation).
  *   `grads` == NULL (both n3dt_render_bwd and n3dt_neural_render_bwd): the network is FROZEN, as in single-image fitting
  *   (FittingSingleImage_new.py:826-859 optimises codes and cameras only) -- no parameter gradient is computed, only the
  *   gradients of the inputs (d_bg_featmap must then be NULL too). */
@@ -232,13 +255,13 @@ size_t n3dt_render_train_workspace_bytes(const N3dtGeom* g);
 int n3dt_render_train_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, const N3dtMlpParams* p,
                           const float* xy, const float* R, const float* T, const float* Kinv,
                           const float* shape, const float* appea, const float* audio, const float* t_rand,
-                          const float* bg_featmap, float* fg_feat, float* bg_alpha, float* depth, float* merge_feat,
+                          const float* bg_featmap, const float* ray_bias, float* fg_feat, float* bg_alpha, float* depth, float* merge_feat,
                           void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream);
 int n3dt_render_bwd(const N3dtGeom* g, int precision, const N3dtMlpParams* p, const N3dtMlpGrads* grads,
                     const float* shape, const float* appea, const float* audio, const float* bg_featmap,
                     const float* d_merge_feat, const float* d_fg_feat, const float* d_bg_alpha,
                     const void* saved, size_t saved_bytes,
-                    float* d_bg_featmap, float* d_shape, float* d_appea, float* d_audio,
+                    float* d_bg_featmap, float* d_shape, float* d_appea, float* d_audio, float* d_ray_bias,
                     const float* xy, const float* R, const float* T, const float* Kinv, const float* t_rand,
                     float* d_R, float* d_T,
                     void* workspace, size_t workspace_bytes, void* stream);

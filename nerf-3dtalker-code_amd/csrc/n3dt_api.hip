@@ -20,6 +20,9 @@ void n3dt_launch_ray_head(const N3dtGeom*, int, int, const float*, const float*,
 void n3dt_launch_ray_head_mfma(const N3dtGeom*, int, int, const float*, const float*, const float*, const float*, int, float*, float*,
                                float*, float*, float*, float*, hipStream_t);
 void n3dt_launch_chw_to_hwc(int, int, const float*, float*, hipStream_t);
+void n3dt_launch_rayfold(const N3dtGeom*, const float*, const float*, hipStream_t);
+void n3dt_launch_ray_vd_bias(const N3dtGeom*, const float*, long, const float*, const float*, const float*, float*, hipStream_t);
+void n3dt_launch_embed_freqs(int, size_t, int, const float*, float*, hipStream_t);
 void n3dt_launch_sample_points(const N3dtGeom*, const float*, const float*, const float*, const float*, const float*, float*, float*,
                                float*, float*, float*, hipStream_t);
 void n3dt_launch_embed(int, size_t, const float*, float*, hipStream_t);
@@ -42,18 +45,20 @@ size_t n3dt_train_saved_floats(const N3dtGeom*);
 size_t n3dt_train_ws_floats(const N3dtGeom*);
 void n3dt_launch_train_fwd(const N3dtGeom*, const N3dtMlpParams*, const float*, const float*, const float*, const float*, const float*,
                            const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, float*,
-                           float*, hipStream_t);
+                           float*, const float* /*ray_bias*/, hipStream_t);
 void n3dt_launch_train_bwd(const N3dtGeom*, const N3dtMlpParams*, const N3dtMlpGrads*, const float*, const float*, const float*,
                            const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*,
-                           const float*, const float*, const float*, const float*, const float*, float*, float*, float*, hipStream_t);
+                           const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float* /*d_ray_bias*/,
+                           hipStream_t);
 size_t n3dt_train16_saved_bytes(const N3dtGeom*);
 size_t n3dt_train16_ws_bytes(const N3dtGeom*);
 void n3dt_launch_train16_fwd(const N3dtGeom*, const N3dtMlpParams*, const void*, const float*, const float*, const float*, const float*,
                              const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*,
-                             float*, void*, void*, hipStream_t);
+                             float*, void*, void*, const float* /*ray_bias*/, hipStream_t);
 void n3dt_launch_train16_bwd(const N3dtGeom*, const N3dtMlpParams*, const N3dtMlpGrads*, const float*, const float*, const float*,
                              const float*, const float*, const float*, const float*, const void*, float*, float*, float*, float*,
-                             const float*, const float*, const float*, const float*, const float*, float*, float*, void*, hipStream_t);
+                             const float*, const float*, const float*, const float*, const float*, float*, float*, void*, float* /*d_ray_bias*/,
+                             hipStream_t);
 void n3dt_launch_img_to_uint8(int, int, const float*, unsigned char*, hipStream_t);
 void n3dt_launch_loss_fwd(int, int, const float*, const float*, const float*, const float*, float, float*, float*, hipStream_t);
 void n3dt_launch_loss_bwd(int, int, const float*, const float*, const float*, const float*, float, const float*, const float*, const float*, float*,
@@ -93,6 +98,15 @@ static int check_geom(const N3dtGeom* g, int precision) {
     if (g->feat_nc != 256) return fail(N3DT_EINVAL, "only featmap_nc == 256 is built");
     if (g->shape_dim < 1 || g->appea_dim < 1 || g->audio_dim < 0) return fail(N3DT_EINVAL, "bad latent widths");
     if (g->shape_dim + g->audio_dim > 512 || g->appea_dim > 512) return fail(N3DT_EINVAL, "latent width > 512");
+    if (g->vd_dim != 0 && g->vd_dim != 27) return fail(N3DT_EINVAL, "vd_dim must be 0 or 27 (include_vd: 3 + 6 * 4 channels)");
+    return N3DT_OK;
+}
+// include_vd: the per-ray bias must come with the flag, and only with it
+static int check_ray_bias(const N3dtGeom* g, const void* ray_bias, const char* who) {
+    if ((g->vd_dim > 0) != (ray_bias != nullptr)) {
+        snprintf(g_err, sizeof(g_err), "%s: the per-ray bias must be given iff vd_dim > 0", who);
+        return N3DT_EINVAL;
+    }
     return N3DT_OK;
 }
 
@@ -123,7 +137,7 @@ static RenderCarve render_carve(const N3dtGeom* g, int precision) {
     c.bpr = (g->n_samples + c.bs - 1) / c.bs;
     const size_t blocks = (size_t)g->batch * g->n_rays * c.bpr;
     c.fold = 0;
-    c.part = align256((size_t)g->batch * N3DT_FOLD_STRIDE * sizeof(float));
+    c.part = align256(n3dt_fold_region_floats(g->batch, g->n_rays, g->vd_dim) * sizeof(float));  // (+ the per-ray table of include_vd)
     c.wlocal = c.part + align256(blocks * (192 + 4) * sizeof(float));
     c.bghwc = c.wlocal + align256(blocks * c.bs * sizeof(float));  // the background map transposed to [N_r][C] for the merge
     c.total = c.bghwc + align256((size_t)g->n_rays * g->feat_nc * sizeof(float));
@@ -212,11 +226,12 @@ extern "C" size_t n3dt_render_workspace_bytes(const N3dtGeom* g, int precision) 
 
 extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, const N3dtMlpParams* p, const float* xy,
                                const float* R, const float* T, const float* Kinv, const float* shape, const float* appea,
-                               const float* audio, const float* t_rand, const float* bg_featmap, float* fg_feat,
+                               const float* audio, const float* t_rand, const float* bg_featmap, const float* ray_bias, float* fg_feat,
                                float* bg_alpha, float* depth, float* weight, float* merge_feat, void* workspace,
                                size_t workspace_bytes, void* stream) {
     int rc = check_geom(g, precision);
     if (rc) return rc;
+    if ((rc = check_ray_bias(g, ray_bias, "n3dt_render_fwd")) != N3DT_OK) return rc;
     if (!packed_mlp || !p || !xy || !R || !T || !Kinv || !shape || !appea || !workspace)
         return fail(N3DT_EINVAL, "n3dt_render_fwd: NULL argument");
     if (!fg_feat && !merge_feat) return fail(N3DT_EINVAL, "n3dt_render_fwd: neither fg_feat nor merge_feat requested");
@@ -231,12 +246,13 @@ extern "C" int n3dt_render_fwd(const N3dtGeom* g, int precision, const void* pac
     float* part = (float*)(ws + c.part);
     float* wlocal = (float*)(ws + c.wlocal);
     n3dt_launch_fold(g, p, shape, appea, audio, fold, precision != N3DT_F32, s);
+    if (ray_bias) n3dt_launch_rayfold(g, fold, ray_bias, s);
     const int span = n3dt_prof_span_begin(s);
     if (precision == N3DT_F32)
         n3dt_launch_nerf_fwd_f32(g, p, packed_mlp, fold, xy, R, T, Kinv, t_rand, part, weight ? wlocal : nullptr, s);
     else if (precision == N3DT_BF16X3)
         n3dt_launch_nerf_fwd_x16s(g, packed_mlp, fold, xy, R, T, Kinv, t_rand, part, weight ? wlocal : nullptr, s);
-    else if (x16_tiling() == 3)
+    else if (x16_tiling() == 3 && g->vd_dim == 0)
         n3dt_launch_nerf_fwd_x16b(g, precision, (const unsigned char*)packed_mlp + n3dt_packed_region_b_offset(precision), fold, xy, R, T,
                                   Kinv, t_rand, part, weight ? wlocal : nullptr, s);
     else
@@ -270,6 +286,22 @@ extern "C" int n3dt_embed(int batch, size_t m, const float* pts, float* pe, void
     if (batch < 1 || m < 1 || !pts || !pe) return fail(N3DT_EINVAL, "n3dt_embed: bad argument");
     n3dt_launch_embed(batch, m, pts, pe, (hipStream_t)stream);
     return check_hip("n3dt_embed");
+}
+
+extern "C" int n3dt_embed_freqs(int batch, size_t m, int n_freqs, const float* pts, float* pe, void* stream) {
+    if (batch < 1 || m < 1 || n_freqs < 1 || n_freqs > 16 || !pts || !pe) return fail(N3DT_EINVAL, "n3dt_embed_freqs: bad argument");
+    n3dt_launch_embed_freqs(batch, m, n_freqs, pts, pe, (hipStream_t)stream);
+    return check_hip("n3dt_embed_freqs");
+}
+
+extern "C" int n3dt_ray_vd_bias(const N3dtGeom* g, const float* w_vd, int64_t ld_w, const float* xy, const float* R, const float* Kinv,
+                                float* ray_bias, void* stream) {
+    int rc = check_geom(g, N3DT_F32);
+    if (rc) return rc;
+    if (g->vd_dim != 27) return fail(N3DT_EINVAL, "n3dt_ray_vd_bias: vd_dim must be 27");
+    if (!w_vd || ld_w < 27 || !xy || !R || !Kinv || !ray_bias) return fail(N3DT_EINVAL, "n3dt_ray_vd_bias: bad argument");
+    n3dt_launch_ray_vd_bias(g, w_vd, (long)ld_w, xy, R, Kinv, ray_bias, (hipStream_t)stream);
+    return check_hip("n3dt_ray_vd_bias");
 }
 
 extern "C" size_t n3dt_mlp_points_workspace_bytes(const N3dtGeom* g, size_t m) {
@@ -387,11 +419,12 @@ extern "C" size_t n3dt_render_train_workspace_bytes(const N3dtGeom* g) {
 
 extern "C" int n3dt_render_train_fwd(const N3dtGeom* g, int precision, const void* packed_mlp, const N3dtMlpParams* p, const float* xy, const float* R,
                                      const float* T, const float* Kinv, const float* shape, const float* appea, const float* audio,
-                                     const float* t_rand, const float* bg_featmap, float* fg_feat, float* bg_alpha, float* depth,
-                                     float* merge_feat, void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                                     const float* t_rand, const float* bg_featmap, const float* ray_bias, float* fg_feat, float* bg_alpha,
+                                     float* depth, float* merge_feat, void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
                                      void* stream) {
     int rc = check_train_geom(g);
     if (rc) return rc;
+    if ((rc = check_ray_bias(g, ray_bias, "n3dt_render_train_fwd")) != N3DT_OK) return rc;
     if (precision != N3DT_F32 && precision != N3DT_BF16) return fail(N3DT_EINVAL, "training precision must be N3DT_F32 or N3DT_BF16");
     if (!packed_mlp || !p || !xy || !R || !T || !Kinv || !shape || !appea || !fg_feat || !saved || !workspace)
         return fail(N3DT_EINVAL, "n3dt_render_train_fwd: NULL argument");
@@ -404,22 +437,23 @@ extern "C" int n3dt_render_train_fwd(const N3dtGeom* g, int precision, const voi
     const float* tail = (const float*)((const unsigned char*)packed_mlp + n3dt_packed_tail_offset(precision));
     if (precision == N3DT_BF16) {
         n3dt_launch_train16_fwd(g, p, packed_mlp, tail, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap, fg_feat, bg_alpha, depth,
-                                merge_feat, saved, workspace, (hipStream_t)stream);
+                                merge_feat, saved, workspace, ray_bias, (hipStream_t)stream);
         return check_hip("n3dt_render_train_fwd");
     }
     n3dt_launch_train_fwd(g, p, tail, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap, fg_feat, bg_alpha, depth, merge_feat,
-                          (float*)saved, (float*)workspace, (hipStream_t)stream);
+                          (float*)saved, (float*)workspace, ray_bias, (hipStream_t)stream);
     return check_hip("n3dt_render_train_fwd");
 }
 
 extern "C" int n3dt_render_bwd(const N3dtGeom* g, int precision, const N3dtMlpParams* p, const N3dtMlpGrads* grads, const float* shape,
                                const float* appea, const float* audio, const float* bg_featmap, const float* d_merge_feat,
                                const float* d_fg_feat, const float* d_bg_alpha, const void* saved, size_t saved_bytes,
-                               float* d_bg_featmap, float* d_shape, float* d_appea, float* d_audio, const float* xy, const float* R,
-                               const float* T, const float* Kinv, const float* t_rand, float* d_R, float* d_T, void* workspace,
+                               float* d_bg_featmap, float* d_shape, float* d_appea, float* d_audio, float* d_ray_bias, const float* xy,
+                               const float* R, const float* T, const float* Kinv, const float* t_rand, float* d_R, float* d_T, void* workspace,
                                size_t workspace_bytes, void* stream) {
     int rc = check_train_geom(g);
     if (rc) return rc;
+    if ((rc = check_ray_bias(g, d_ray_bias, "n3dt_render_bwd")) != N3DT_OK) return rc;
     if (precision != N3DT_F32 && precision != N3DT_BF16) return fail(N3DT_EINVAL, "training precision must be N3DT_F32 or N3DT_BF16");
     if (!p || !shape || !appea || !saved || !workspace) return fail(N3DT_EINVAL, "n3dt_render_bwd: NULL argument");
     if (!d_merge_feat && !d_fg_feat && !d_bg_alpha) return fail(N3DT_EINVAL, "n3dt_render_bwd: no incoming gradient");
@@ -435,11 +469,11 @@ extern "C" int n3dt_render_bwd(const N3dtGeom* g, int precision, const N3dtMlpPa
     if ((d_R || d_T) && (!xy || !R || !T || !Kinv)) return fail(N3DT_EINVAL, "n3dt_render_bwd: camera gradients need xy, R, T, Kinv");
     if (precision == N3DT_BF16) {
         n3dt_launch_train16_bwd(g, p, grads, shape, appea, audio, bg_featmap, d_merge_feat, d_fg_feat, d_bg_alpha, saved, d_bg_featmap,
-                                d_shape, d_appea, d_audio, xy, R, T, Kinv, t_rand, d_R, d_T, workspace, (hipStream_t)stream);
+                                d_shape, d_appea, d_audio, xy, R, T, Kinv, t_rand, d_R, d_T, workspace, d_ray_bias, (hipStream_t)stream);
         return check_hip("n3dt_render_bwd");
     }
     n3dt_launch_train_bwd(g, p, grads, shape, appea, audio, bg_featmap, d_merge_feat, d_fg_feat, d_bg_alpha, (const float*)saved,
-                          d_bg_featmap, d_shape, d_appea, d_audio, xy, R, T, Kinv, t_rand, d_R, d_T, (float*)workspace,
+                          d_bg_featmap, d_shape, d_appea, d_audio, xy, R, T, Kinv, t_rand, d_R, d_T, (float*)workspace, d_ray_bias,
                           (hipStream_t)stream);
     return check_hip("n3dt_render_bwd");
 }

@@ -81,3 +81,12 @@ __host__ __device__ inline size_t n3dt_packed_tail_offset(int precision) {
 __host__ __device__ inline int n3dt_bias_offset(int stage) {
     return stage <= 8 ? 384 * stage : (stage == 9 ? 384 * 8 + 32 : 384 * 9 + 32);
 }
+
+// include_vd (N3dtGeom.vd_dim > 0): RGB_layer_1's bias is per RAY -- the frame's folded entry + the caller's `ray_bias` term --
+// in a table [B * N_r][192] that sits right behind the fold table wherever that lives (render workspace, the training paths'
+// saved buffers), so that the fused kernels find it from the `fold` pointer they already take.
+#define N3DT_RAYFOLD_STRIDE 192
+__host__ __device__ inline size_t n3dt_rayfold_offset(int batch) { return ((size_t)batch * N3DT_FOLD_STRIDE + 63) & ~(size_t)63; }  // floats
+__host__ __device__ inline size_t n3dt_fold_region_floats(int batch, int n_rays, int vd_dim) {
+    return vd_dim > 0 ? n3dt_rayfold_offset(batch) + (size_t)batch * n_rays * N3DT_RAYFOLD_STRIDE : (size_t)batch * N3DT_FOLD_STRIDE;
+}

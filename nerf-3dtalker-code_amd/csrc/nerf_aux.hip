@@ -276,6 +276,71 @@ extern "C" void n3dt_launch_fold(const N3dtGeom* g, const N3dtMlpParams* p, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// include_vd (NetWorks/HeadNeRFNet.py:56-63,86,141-142): RGB_layer_1's view-direction columns as a per-ray bias.
+//   rayfold[ray][o] = fold[frame(ray)][bias_offset(10) + o] + ray_bias[ray][o]      (what the fused kernels read, n3dt_layout.h)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rayfold_kernel(int n_rays, long total, const float* __restrict__ fold, const float* __restrict__ ray_bias,
+                                                      float* __restrict__ rayfold) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over rays x 48 (four outputs per thread)
+    if (i >= total * 48) return;
+    const long ray = i / 48;
+    const int o = (int)(i % 48) * 4;
+    const f32x4 f = *reinterpret_cast<const f32x4*>(fold + (size_t)(ray / n_rays) * N3DT_FOLD_STRIDE + n3dt_bias_offset(10) + o);
+    const f32x4 r = *reinterpret_cast<const f32x4*>(ray_bias + (size_t)ray * N3DT_RAYFOLD_STRIDE + o);
+    *reinterpret_cast<f32x4*>(rayfold + (size_t)ray * N3DT_RAYFOLD_STRIDE + o) = f32x4{f[0] + r[0], f[1] + r[1], f[2] + r[2], f[3] + r[3]};
+}
+extern "C" void n3dt_launch_rayfold(const N3dtGeom* g, const float* fold, const float* ray_bias, hipStream_t s) {
+    const long total = (long)g->batch * g->n_rays;
+    float* rayfold = const_cast<float*>(fold) + n3dt_rayfold_offset(g->batch);
+    hipLaunchKernelGGL(rayfold_kernel, dim3((unsigned)((total * 48 + 255) / 256)), dim3(256), 0, s, g->n_rays, total, fold, ray_bias, rayfold);
+}
+
+// ray_bias[ray][o] = sum_j w_vd[o][j] * Embedder_4(d(ray))[j]: direction as GenSamplePoints (utils.py:149-153), the encoder's
+// channel order [d, sin(2^0 d), cos(2^0 d), ..., sin(2^3 d), cos(2^3 d)] (utils.py:20-51), accurate sinf / cosf, the 27 products
+// of an output summed in ascending j (fp32 FMAs).  One wave per ray: lane o and o + 64, o + 128 own three outputs.
+__global__ __launch_bounds__(256) void ray_vd_bias_kernel(N3dtGeom g, const float* __restrict__ w_vd, long ld_w, const float* __restrict__ xy,
+                                                          const float* __restrict__ R, const float* __restrict__ Kinv,
+                                                          float* __restrict__ ray_bias) {
+    __shared__ float wl[192 * 27];
+    for (int i = threadIdx.x; i < 192 * 27; i += blockDim.x) wl[i] = w_vd[(size_t)(i / 27) * ld_w + i % 27];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long total = (long)g.batch * g.n_rays;
+    for (long rayg = (long)blockIdx.x * 4 + wave; rayg < total; rayg += (long)gridDim.x * 4) {
+        const int b = (int)(rayg / g.n_rays), ray = (int)(rayg % g.n_rays);
+        const float x = xy[(int64_t)b * g.xy_stride_b + 0 * g.xy_stride_c + (int64_t)ray * g.xy_stride_r];
+        const float y = xy[(int64_t)b * g.xy_stride_b + 1 * g.xy_stride_c + (int64_t)ray * g.xy_stride_r];
+        float d[3], l;
+        n3dt_ray_setup(R + b * 9, Kinv + b * 9, x, y, d, l);
+        float pe[27];
+        pe[0] = d[0]; pe[1] = d[1]; pe[2] = d[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float a = d[i] * (float)(1 << k);
+                pe[3 + 6 * k + i] = sinf(a);
+                pe[3 + 6 * k + 3 + i] = cosf(a);
+            }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int o = lane + 64 * u;
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 27; ++j) acc = fmaf(wl[o * 27 + j], pe[j], acc);
+            ray_bias[(size_t)rayg * N3DT_RAYFOLD_STRIDE + o] = acc;
+        }
+    }
+}
+extern "C" void n3dt_launch_ray_vd_bias(const N3dtGeom* g, const float* w_vd, long ld_w, const float* xy, const float* R, const float* Kinv,
+                                        float* ray_bias, hipStream_t s) {
+    const long total = (long)g->batch * g->n_rays;
+    long grid = (total + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(ray_vd_bias_kernel, dim3((unsigned)grid), dim3(256), 0, s, *g, w_vd, ld_w, xy, R, Kinv, ray_bias);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Per-ray head.  Combines the per-block partials front to back (the transmittance of a later
 // block is scaled by the product of the earlier blocks' (1 - alpha + 1e-10) factors: the same
 // cumprod as NetWorks/utils.py:283-287, re-associated), then applies RGB_layer_2 once per ray:

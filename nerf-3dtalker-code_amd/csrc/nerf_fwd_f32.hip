@@ -100,7 +100,9 @@ __global__ __launch_bounds__(F32_WAVES * 64, 1) void nerf_fwd_f32_kernel(
     // density head (models.py:78; relu applied below), then the feature head (:79-82)
     f32_layer<384>(packed + n3dt_stage_offset(8), fb + n3dt_bias_offset(8), 32, false, h, den, lane);
     f32_layer<384>(packed + n3dt_stage_offset(9), fb + n3dt_bias_offset(9), 384, false, h, h, lane);
-    f32_layer<384>(packed + n3dt_stage_offset(10), fb + n3dt_bias_offset(10), 192, true, h, h, lane);
+    // include_vd: RGB_layer_1's bias of this wave's RAY (frame entry + view-direction term, n3dt_layout.h) instead of the frame's
+    const float* b10 = g.vd_dim > 0 ? fold + n3dt_rayfold_offset(g.batch) + (size_t)rayg * N3DT_RAYFOLD_STRIDE : fb + n3dt_bias_offset(10);
+    f32_layer<384>(packed + n3dt_stage_offset(10), b10, 192, true, h, h, lane);
 
     // compositing of this 16-sample block (utils.py:273-309): local transmittance starts at 1
     float sigma = fmaxf(den[c], 0.0f);

@@ -243,6 +243,7 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
     float dist[NB], zval[NB];
     frag pe[NB][4];
     int frame = 0;
+    long ray0 = 0;  // the global ray of the wave's first block (include_vd: NB = 1, so the wave's only ray)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         long bidx = ((long)blockIdx.x * WAVES + wave) * NB + nb;
@@ -254,7 +255,7 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
         const long rayg = bidx / bpr;
         const int ray = (int)(rayg % g.n_rays);
         const int b = (int)(rayg / g.n_rays);
-        if (nb == 0) frame = b;
+        if (nb == 0) frame = b, ray0 = rayg;
         float p[3];
         n3dt_sample_point(g, xy, R, T, Kinv, t_rand, b, ray, sb * X16_BS + c, p, dist[nb], zval[nb]);
         // phase in revolutions as hi + lo, so that the 2^k scaling of the encoder stays exact
@@ -277,6 +278,12 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
         }
     }
     const float* fb = fold + (size_t)__builtin_amdgcn_readfirstlane(frame) * N3DT_FOLD_STRIDE;
+    // include_vd: the merged RGB stage's bias is per RAY (frame entry + view-direction term; the table sits behind the fold table,
+    // n3dt_layout.h).  The launcher picks the one-block-per-wave tiling then, so the wave has one ray.
+    const float* b10 = fb + n3dt_bias_offset(10);
+    if constexpr (NB == 1) {
+        if (g.vd_dim > 0) b10 = fold + n3dt_rayfold_offset(g.batch) + (size_t)__builtin_amdgcn_readfirstlane((int)ray0) * N3DT_RAYFOLD_STRIDE;
+    }
     X16SaveStage<PREC> svs;
     unsigned char* xT_blk = nullptr;  // this block's xT tiles (+ the lane's image offset)
     // record of this block in the saved buffers; a dead wave writes the dump record behind the last block (every wave must
@@ -307,7 +314,7 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
     // the bias slot of SAVE stage number k (0 .. 8), after staging the table of the stage that follows it
     auto bias_slot = [&](const int k, const int next_table, const int next_n) -> unsigned {
         if constexpr (SAVE && X16_SAVE_LDS_BIAS) {
-            if (next_table >= 0) bl.stage_in(fb + n3dt_bias_offset(next_table), next_n, (k + 1) & 1, lane);
+            if (next_table >= 0) bl.stage_in(next_table == 10 ? b10 : fb + n3dt_bias_offset(next_table), next_n, (k + 1) & 1, lane);
             return bl.addr + (k & 1) * X16_BIAS_SLOT;
         } else {
             return 0u;
@@ -371,7 +378,7 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
         svs.tile0 = tsv.gS + (size_t)rec * 12 * X16_PIECE + lane * 16;
         svs.gate0 = nullptr;
     }
-    x16_stage<PREC, NB, WAVES, 24, 0, 6, MODE_COMPOSITE, SAVE>(ws, fb + n3dt_bias_offset(10), pe, nullptr, hb, ha, aux, po, live, lane,
+    x16_stage<PREC, NB, WAVES, 24, 0, 6, MODE_COMPOSITE, SAVE>(ws, b10, pe, nullptr, hb, ha, aux, po, live, lane,
                                                                      SAVE ? &svs : nullptr, 0, bias_slot(8, -1, 0));
 #ifdef X16_STAMP
     if (wlocal && lane == 0 && live[0]) {
@@ -448,7 +455,8 @@ extern "C" void n3dt_launch_nerf_fwd_x16(const N3dtGeom* g, int precision, const
         return e ? atoi(e) : X16_DEFAULT_TILING;
     }();
     const long blocks = (long)g->batch * g->n_rays * ((g->n_samples + X16_BS - 1) / X16_BS);
-    const bool use_wide = wide == 2 && (((long)g->n_rays * ((g->n_samples + X16_BS - 1) / X16_BS)) % 2 == 0) && blocks >= 2;
+    // (include_vd: the bias of the RGB stage is per ray, so a wave must not span two rays: the one-block-per-wave tiling)
+    const bool use_wide = wide == 2 && g->vd_dim == 0 && (((long)g->n_rays * ((g->n_samples + X16_BS - 1) / X16_BS)) % 2 == 0) && blocks >= 2;
     if (precision == N3DT_BF16) {
         if (use_wide) launch_x16<N3DT_BF16, 2, 4>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, stream);
         else launch_x16<N3DT_BF16, 1, 8>(g, packed, fold, xy, R, T, Kinv, t_rand, part, wlocal, stream);

@@ -220,7 +220,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerf_fwd_x16b_kernel(
         aux[1] = w1;
     }
     // RGB_layer_0 -> RGB_layer_1 as ONE merged 192 x 384 layer on h7, relu, weighted by the sample weights and reduced
-    x16b_stage<PREC, WAVES, 12, 0, 12, B_COMPOSITE>(ws, fb + n3dt_bias_offset(10), pe, nullptr, hb, ha, aux, po, live, lane);
+    const float* b10 = g.vd_dim > 0 ? fold + n3dt_rayfold_offset(g.batch) + (size_t)__builtin_amdgcn_readfirstlane((int)rayg) * N3DT_RAYFOLD_STRIDE
+                                    : fb + n3dt_bias_offset(10);  // include_vd: per ray (n3dt_layout.h)
+    x16b_stage<PREC, WAVES, 12, 0, 12, B_COMPOSITE>(ws, b10, pe, nullptr, hb, ha, aux, po, live, lane);
 }
 
 template <int PREC>

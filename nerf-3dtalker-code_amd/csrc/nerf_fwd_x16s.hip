@@ -194,7 +194,10 @@ __global__ __launch_bounds__(XS_WAVES * 64, 1) void nerf_fwd_x16s_kernel(
     }
     // RGB_layer_0 -> RGB_layer_1 as ONE merged 192 x 384 layer on h7 (no activation sits between them, models.py:79-81; merged
     // matrix and bias built by pack / fold), relu, weighted by the sample weights and reduced over the samples
-    xs_stage<24, 0, 6, MODE_COMPOSITE>(ws, fb + n3dt_bias_offset(10), pe_lds, hb_hi, hb_lo, ha_hi, ha_lo, aux, po, live, lane);
+    // include_vd: the merged RGB bias of this wave's RAY (n3dt_layout.h) instead of the frame's
+    const float* b10 = g.vd_dim > 0 ? fold + n3dt_rayfold_offset(g.batch) + (size_t)__builtin_amdgcn_readfirstlane((int)rayg) * N3DT_RAYFOLD_STRIDE
+                                    : fb + n3dt_bias_offset(10);
+    xs_stage<24, 0, 6, MODE_COMPOSITE>(ws, b10, pe_lds, hb_hi, hb_lo, ha_hi, ha_lo, aux, po, live, lane);
 }
 
 extern "C" void n3dt_launch_nerf_fwd_x16s(const N3dtGeom* g, const void* packed, const float* fold, const float* xy, const float* R,

@@ -63,6 +63,26 @@ extern "C" void n3dt_launch_embed(int B, size_t M, const float* pts, float* pe, 
     hipLaunchKernelGGL(seam_embed_kernel, dim3((unsigned)(((size_t)B * M + 255) / 256)), dim3(256), 0, s, B, M, pts, pe);
 }
 
+// the same encoder with n_freqs frequencies: pts [B,3,M] -> pe [B, 3 + 6 n_freqs, M] (n_freqs = 4: the reference's vd_encoder,
+// NetWorks/HeadNeRFNet.py:30-31,61)
+__global__ void seam_embed_freqs_kernel(int B, size_t M, int n_freqs, const float* __restrict__ pts, float* __restrict__ pe) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * M) return;
+    const size_t b = i / M, m = i % M;
+    const int rows = 3 + 6 * n_freqs;
+    const float p[3] = {pts[(b * 3 + 0) * M + m], pts[(b * 3 + 1) * M + m], pts[(b * 3 + 2) * M + m]};
+    for (int r = 0; r < 3; ++r) pe[(b * rows + r) * M + m] = p[r];
+    for (int k = 0; k < n_freqs; ++k)
+        for (int d = 0; d < 3; ++d) {
+            const float a = p[d] * (float)(1 << k);
+            pe[(b * rows + 3 + 6 * k + d) * M + m] = sinf(a);
+            pe[(b * rows + 3 + 6 * k + 3 + d) * M + m] = cosf(a);
+        }
+}
+extern "C" void n3dt_launch_embed_freqs(int B, size_t M, int n_freqs, const float* pts, float* pe, hipStream_t s) {
+    hipLaunchKernelGGL(seam_embed_freqs_kernel, dim3((unsigned)(((size_t)B * M + 255) / 256)), dim3(256), 0, s, B, M, n_freqs, pts, pe);
+}
+
 // ---- MLPforNeRF ----------------------------------------------------------------------------------
 // channel-major [B][C][M] -> point-major rows dst[(b*M + m) * ld + col0 + c]
 __global__ void seam_to_rows_kernel(int B, int C, size_t M, const float* __restrict__ src, float* __restrict__ dst, long ld, int col0) {

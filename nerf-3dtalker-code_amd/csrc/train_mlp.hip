@@ -42,7 +42,7 @@ static TrainSaved saved_layout(const N3dtGeom* g) {
     s.g = o; o += al64(P * 192);
     s.w = o; o += al64(P);
     s.ray = o; o += al64(R * N3DT_PART_STRIDE);  // per ray: G[192], wsum, dsum, tprod, pad
-    s.fold = o; o += al64((size_t)g->batch * N3DT_FOLD_STRIDE);
+    s.fold = o; o += al64(n3dt_fold_region_floats(g->batch, g->n_rays, g->vd_dim));  // (+ the per-ray RGB_layer_1 bias table of include_vd)
     s.total = o;
     return s;
 }
@@ -598,6 +598,7 @@ __global__ void train_unpack_grads_kernel(N3dtMlpGrads gp, int S, const float* _
 // orchestration
 // ---------------------------------------------------------------------------------------------
 extern "C" void n3dt_launch_fold(const N3dtGeom*, const N3dtMlpParams*, const float*, const float*, const float*, float*, int, hipStream_t);
+extern "C" void n3dt_launch_rayfold(const N3dtGeom*, const float*, const float*, hipStream_t);
 extern "C" void n3dt_launch_ray_head(const N3dtGeom*, int, int, const float*, const float*, const float*, const float*, int, float*,
                                      float*, float*, float*, float*, hipStream_t);
 
@@ -632,7 +633,7 @@ static int split_for(long K) {
 extern "C" void n3dt_launch_train_fwd(const N3dtGeom* g, const N3dtMlpParams* p, const float* tail, const float* xy, const float* R,
                                       const float* T, const float* Kinv, const float* shape, const float* appea, const float* audio,
                                       const float* t_rand, const float* bg_featmap, float* fg_feat, float* bg_alpha, float* depth,
-                                      float* merge_feat, float* saved, float* ws, hipStream_t s) {
+                                      float* merge_feat, float* saved, float* ws, const float* ray_bias, hipStream_t s) {
     const TrainSaved sv = saved_layout(g);
     const TrainWs wl = ws_layout(g);
     const int P = g->batch * g->n_rays * g->n_samples, ppf = g->n_rays * g->n_samples;
@@ -640,6 +641,7 @@ extern "C" void n3dt_launch_train_fwd(const N3dtGeom* g, const N3dtMlpParams* p,
     float* fold = saved + sv.fold;
     float* cat5 = saved + sv.cat5;
     n3dt_launch_fold(g, p, shape, appea, audio, fold, 0, s);
+    if (ray_bias) n3dt_launch_rayfold(g, fold, ray_bias, s);  // include_vd: RGB_layer_1's bias per ray
     hipLaunchKernelGGL(train_pack_kernel, dim3((385 * 384 + 384 * 448 + 255) / 256), dim3(256), 0, s, *p, S, ws + wl.w5p, ws + wl.wc,
                        ws + wl.bc);
     hipLaunchKernelGGL(train_sample_pe_kernel, dim3((unsigned)(((size_t)P * 4 + 255) / 256)), dim3(256), 0, s, *g, xy, R, T, Kinv, t_rand,
@@ -666,6 +668,9 @@ extern "C" void n3dt_launch_train_fwd(const N3dtGeom* g, const N3dtMlpParams* p,
     {   // RGB_layer_1 (+ folded appearance), relu (models.py:80-81)
         Gemm32 q = mk(P, 192, 384, saved + sv.xr, XR_LD, 0, p->weight[10], 384 + A, 0, saved + sv.g, 192);
         q.bias = fold + n3dt_bias_offset(10); q.bias_group_rows = ppf; q.bias_ld = N3DT_FOLD_STRIDE; q.act = G32_ACT_RELU;
+        if (ray_bias) {  // include_vd: one bias row per ray (the samples of a ray are consecutive rows)
+            q.bias = fold + n3dt_rayfold_offset(g->batch); q.bias_group_rows = g->n_samples; q.bias_ld = N3DT_RAYFOLD_STRIDE;
+        }
         n3dt_gemm32(q, s);
     }
     const long Rr = (long)g->batch * g->n_rays;
@@ -678,7 +683,8 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
                                       const float* appea, const float* audio, const float* bg_featmap, const float* d_merge,
                                       const float* d_fg, const float* d_ba, const float* saved, float* d_bg_featmap, float* d_shape,
                                       float* d_appea, float* d_audio, const float* xy, const float* Rm, const float* Tv,
-                                      const float* Kinv, const float* t_rand, float* d_R, float* d_T, float* ws, hipStream_t s) {
+                                      const float* Kinv, const float* t_rand, float* d_R, float* d_T, float* ws, float* d_ray_bias,
+                                      hipStream_t s) {
     const TrainSaved sv = saved_layout(g);
     const TrainWs wl = ws_layout(g);
     const int P = g->batch * g->n_rays * g->n_samples, ppf = g->n_rays * g->n_samples;
@@ -726,6 +732,10 @@ extern "C" void n3dt_launch_train_bwd(const N3dtGeom* g, const N3dtMlpParams* p,
             n3dt_gemm32(w, s);
         }
         launch_colsum(dG, 192L, ppf, B, 192, dfold + n3dt_bias_offset(10), (long)N3DT_FOLD_STRIDE, s);
+        if (d_ray_bias) {  // include_vd: dL/d(ray_bias) = the same column sums, per ray
+            (void)hipMemsetAsync(d_ray_bias, 0, sizeof(float) * (size_t)Rr * N3DT_RAYFOLD_STRIDE, s);
+            launch_colsum(dG, 192L, g->n_samples, (int)Rr, 192, d_ray_bias, (long)N3DT_RAYFOLD_STRIDE, s);
+        }
     }
     // ---- RGB_layer_0 | density: dH7 = dXR Wc, gated by relu(H7)
     {

@@ -25,7 +25,7 @@ class Geom(ctypes.Structure):
         ("appea_dim", ctypes.c_int32), ("audio_dim", ctypes.c_int32), ("featmap_size", ctypes.c_int32),
         ("n_blocks", ctypes.c_int32), ("world_z1", ctypes.c_float), ("world_z2", ctypes.c_float),
         ("xy_stride_b", ctypes.c_int64), ("xy_stride_c", ctypes.c_int64), ("xy_stride_r", ctypes.c_int64),
-        ("z_planes_given", ctypes.c_int32), ("bg_is_hwc", ctypes.c_int32),
+        ("z_planes_given", ctypes.c_int32), ("bg_is_hwc", ctypes.c_int32), ("vd_dim", ctypes.c_int32),
     ]
 
 
@@ -50,6 +50,7 @@ EXPORTS = [
     "n3dt_neural_render_train_saved_bytes", "n3dt_neural_render_train_workspace_bytes",
     "n3dt_neural_render_train_fwd", "n3dt_neural_render_bwd", "n3dt_loss_fwd", "n3dt_loss_bwd", "n3dt_fine_sample",
     "n3dt_img_to_uint8", "n3dt_sample_points", "n3dt_embed", "n3dt_mlp_points_workspace_bytes", "n3dt_mlp_points", "n3dt_composite",
+    "n3dt_ray_vd_bias", "n3dt_embed_freqs",
     "n3dt_neural_render_pack", "n3dt_neural_render_fwd_reuse", "n3dt_stage_inputs", "n3dt_graph_begin", "n3dt_graph_end", "n3dt_graph_launch", "n3dt_graph_destroy",
 ]
 
@@ -86,7 +87,7 @@ def lib():
     L.n3dt_render_workspace_bytes.restype = sz
     L.n3dt_render_workspace_bytes.argtypes = [ctypes.POINTER(Geom), ci]
     L.n3dt_render_fwd.restype = ci
-    L.n3dt_render_fwd.argtypes = [ctypes.POINTER(Geom), ci, vp, ctypes.POINTER(MlpParams)] + [vp] * 14 + [vp, sz, vp]
+    L.n3dt_render_fwd.argtypes = [ctypes.POINTER(Geom), ci, vp, ctypes.POINTER(MlpParams)] + [vp] * 15 + [vp, sz, vp]
     L.n3dt_neural_render_workspace_bytes.restype = sz
     L.n3dt_neural_render_workspace_bytes.argtypes = [ctypes.POINTER(Geom), ci]
     L.n3dt_neural_render_fwd.restype = ci
@@ -103,9 +104,9 @@ def lib():
     L.n3dt_render_train_workspace_bytes.restype = sz
     L.n3dt_render_train_workspace_bytes.argtypes = [gp]
     L.n3dt_render_train_fwd.restype = ci
-    L.n3dt_render_train_fwd.argtypes = [gp, ci, vp, mp] + [vp] * 13 + [vp, sz, vp, sz, vp]
+    L.n3dt_render_train_fwd.argtypes = [gp, ci, vp, mp] + [vp] * 14 + [vp, sz, vp, sz, vp]
     L.n3dt_render_bwd.restype = ci
-    L.n3dt_render_bwd.argtypes = [gp, ci, mp, mp] + [vp] * 7 + [vp, sz] + [vp] * 11 + [vp, sz, vp]
+    L.n3dt_render_bwd.argtypes = [gp, ci, mp, mp] + [vp] * 7 + [vp, sz] + [vp] * 12 + [vp, sz, vp]
     L.n3dt_neural_render_train_saved_bytes.restype = sz
     L.n3dt_neural_render_train_saved_bytes.argtypes = [gp, ci]
     L.n3dt_neural_render_train_workspace_bytes.restype = sz
@@ -130,6 +131,10 @@ def lib():
     L.n3dt_sample_points.argtypes = [gp] + [vp] * 10 + [vp]
     L.n3dt_embed.restype = ci
     L.n3dt_embed.argtypes = [ci, sz, vp, vp, vp]
+    L.n3dt_embed_freqs.restype = ci
+    L.n3dt_embed_freqs.argtypes = [ci, sz, ci, vp, vp, vp]
+    L.n3dt_ray_vd_bias.restype = ci
+    L.n3dt_ray_vd_bias.argtypes = [gp, vp, ctypes.c_int64, vp, vp, vp, vp, vp]
     L.n3dt_mlp_points_workspace_bytes.restype = sz
     L.n3dt_mlp_points_workspace_bytes.argtypes = [gp, sz]
     L.n3dt_mlp_points.restype = ci
@@ -146,7 +151,7 @@ def lib():
     L.n3dt_graph_launch.argtypes = [vp, vp]
     L.n3dt_graph_destroy.restype = ci
     L.n3dt_graph_destroy.argtypes = [vp]
-    if L.n3dt_abi_version() != 4:
+    if L.n3dt_abi_version() != 5:
         raise N3dtError("libn3dt.so ABI version mismatch")
     _LIB = L
     return L

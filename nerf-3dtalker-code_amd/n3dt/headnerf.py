@@ -233,11 +233,13 @@ def _zeros_like_many(tensors):
 
 class _RenderFn(torch.autograd.Function):
     """a1..a7 with saved activations (n3dt_render_train_fwd) and its backward (n3dt_render_bwd).
-    Inputs after `net`/`geom`: xy, Kinv, t_rand (no grad), then R, T, shape, appea, audio, bg_featmap and the
-    24 MLP parameter tensors (all differentiable; R/T gradients are computed only when they require grad)."""
+    Inputs after `net`/`geom`: xy, Kinv, t_rand (no grad), then R, T, shape, appea, audio, bg_featmap, ray_bias and the
+    24 MLP parameter tensors (all differentiable; R/T gradients are computed only when they require grad).
+    ray_bias [B, N_r, 192] (include_vd, else None): the per-ray addend of RGB_layer_1's pre-activation; the caller forms it from
+    the ray directions with autograd, so its gradient carries on to the 27 view-direction columns and to the cameras."""
 
     @staticmethod
-    def forward(ctx, net, geom, merge_out, xy, Kinv, t_rand, R, T, shape, appea, audio, bg_featmap, *mlp):
+    def forward(ctx, net, geom, merge_out, xy, Kinv, t_rand, R, T, shape, appea, audio, bg_featmap, ray_bias, *mlp):
         """merge_out: None, or a _Slot whose `.t` [B, N_r, C] (a slice of the renderer's input batch) receives the merged
         map and becomes the output.  (Handed over inside a plain object, not as a tensor argument: autograd then sees a fresh
         output, not a modified input.)"""
@@ -258,7 +260,8 @@ class _RenderFn(torch.autograd.Function):
         audio_c = ops._f32c(audio) if geom.audio_dim > 0 else None
         bg = bg_featmap.detach().reshape(geom.feat_nc, -1).contiguous()
         out, saved = ops.render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape_c, appea_c, audio_c, t_rand, bg, ctx.prec,
-                                          merge_out=None if merge_out is None else merge_out.t)
+                                          merge_out=None if merge_out is None else merge_out.t,
+                                          ray_bias=None if ray_bias is None else ops._f32c(ray_bias))
         ctx.geom, ctx.saved, ctx.keep = geom, saved, (ws, bs, shape_c, appea_c, audio_c, bg)
         ctx.cam = (xy, R, T, Kinv, t_rand) if ctx.want_cam else None
         ctx.bg_shape = bg_featmap.shape
@@ -272,34 +275,38 @@ class _RenderFn(torch.autograd.Function):
         geom = ctx.geom
         # gradient buffers: slices of the module's persistent arena (zeroed by one fill per backward pass, and what a
         # multi-GPU step all-reduces in place) -- or fresh zeroed buffers when the arena cannot be used (see FlatGrads.hand_out)
-        if not (any(ctx.needs_input_grad[12:]) or ctx.needs_input_grad[11]):
+        vd = geom.vd_dim > 0
+        if not (any(ctx.needs_input_grad[13:]) or ctx.needs_input_grad[11]):
             # FROZEN network (single-image fitting optimises codes and cameras only, FittingSingleImage_new.py:826-859): no
             # parameter gradient is wanted, so none is computed -- the weight-gradient stage is a quarter of a fitting iteration
-            _, d_shape, d_appea, d_audio, d_R, d_T = ops.render_bwd(geom, ops.mlp_params(ws, bs), None, shape_c, appea_c, audio_c, bg,
-                                                                    d_merge.contiguous(), ctx.saved, ctx.cam, ctx.prec, frozen=True)
+            res = ops.render_bwd(geom, ops.mlp_params(ws, bs), None, shape_c, appea_c, audio_c, bg,
+                                 d_merge.contiguous(), ctx.saved, ctx.cam, ctx.prec, frozen=True)
+            _, d_shape, d_appea, d_audio, d_R, d_T = res[:6]
             ctx.saved = None
             if d_T is not None:
                 d_T = d_T.view(ctx.T_shape)
-            return (None, None, None, None, None, None, d_R, d_T, d_shape, d_appea, d_audio, None, *([None] * len(ctx.mlp_shapes)))
+            return (None, None, None, None, None, None, d_R, d_T, d_shape, d_appea, d_audio, None, res[6] if vd else None,
+                    *([None] * len(ctx.mlp_shapes)))
         views = ctx.net._hand_out_grads(ctx.param_objs)
         if views is None:
             gws, gbs, d_bg_out = _zeros_like_many(ws), _zeros_like_many(bs), None
         else:
             gws = [v.view(w.shape) for v, w in zip(views[:12], ws)]
             gbs, d_bg_out = views[12:24], views[24].view(geom.feat_nc, geom.n_rays)
-        d_bg, d_shape, d_appea, d_audio, d_R, d_T = ops.render_bwd(geom, ops.mlp_params(ws, bs), ops.mlp_params(gws, gbs), shape_c,
-                                                                   appea_c, audio_c, bg, d_merge.contiguous(), ctx.saved, ctx.cam, ctx.prec,
-                                                                   d_bg=d_bg_out)
+        res = ops.render_bwd(geom, ops.mlp_params(ws, bs), ops.mlp_params(gws, gbs), shape_c, appea_c, audio_c, bg, d_merge.contiguous(),
+                             ctx.saved, ctx.cam, ctx.prec, d_bg=d_bg_out)
+        d_bg, d_shape, d_appea, d_audio, d_R, d_T = res[:6]
+        d_ray = res[6] if vd else None
         ctx.saved = None
         grads = [g.view(s) for g, s in zip(gws + gbs, ctx.mlp_shapes)]
         del gws, gbs, views, d_bg_out  # the returned views must be the only references (autograd then adopts them as .grad)
-        if any(ctx.needs_input_grad[12:]) or ctx.needs_input_grad[11]:
+        if any(ctx.needs_input_grad[13:]) or ctx.needs_input_grad[11]:
             # parameter gradients went out: an optimizer step follows, possibly one that leaves the version counters alone
             # (fused Adam) -- void every packed / transposed copy so the next forward of any kind rebuilds them
             ctx.net.invalidate_packed()
         if d_T is not None:
             d_T = d_T.view(ctx.T_shape)
-        return (None, None, None, None, None, None, d_R, d_T, d_shape, d_appea, d_audio, d_bg.view(ctx.bg_shape), *grads)
+        return (None, None, None, None, None, None, d_R, d_T, d_shape, d_appea, d_audio, d_bg.view(ctx.bg_shape), d_ray, *grads)
 
 
 class _Slot:
@@ -467,16 +474,17 @@ class GenSamplePoints(nn.Module):
 
 
 class Embedder(nn.Module):
-    """vp_encoder seam (NetWorks/utils.py:6-51): [B,3,...] -> [B,63,...]."""
+    """vp_encoder / vd_encoder seam (NetWorks/utils.py:6-51): [B,3,...] -> [B, 3 + 6 N_freqs, ...]."""
 
     def __init__(self, N_freqs=10, include_input=True):
         super().__init__()
-        assert N_freqs == 10 and include_input, "the kernels are built for the reference's 10 frequencies + input"
+        assert include_input, "the kernels are built with include_input=True (the reference's only setting)"
         self.N_freqs, self.include_input = N_freqs, include_input
 
     @torch.no_grad()
     def forward(self, x):
-        return ops.embed(x)
+        # 10 frequencies: vp_encoder; 4: vd_encoder (HeadNeRFNet.py:27-31,54,61)
+        return ops.embed(x) if self.N_freqs == 10 else ops.embed_freqs(x, self.N_freqs)
 
 
 class CalcRayColor(nn.Module):
@@ -494,8 +502,9 @@ class HeadNeRFNet(nn.Module):
         # hier_sampling=True: the reference builds FineSample + a second MLP (HeadNeRFNet.py:67-74) but its call site omits
         # two arguments (:182-185) and raises TypeError; here the fine pass runs, with those arguments supplied
         # (inference and training, camera gradients included: test_gradients_through_the_hierarchical_pass_including_the_cameras)
-        if include_vd:
-            raise NotImplementedError("include_vd=True is never used by the reference's callers and not built here")
+        # include_vd=True (HeadNeRFNet.py:56-63,86,141-142; no caller of the reference sets it): RGB_layer_1 takes 27 more input
+        # channels, the 4-frequency encoding of the ray direction.  The direction is constant along a ray, so those columns are a
+        # per-ray bias of the layer (one 27-wide product per ray instead of per point): _vd_ray_bias / ops.ray_vd_bias.
         self.hier_sampling = hier_sampling
         self.include_vd = include_vd
         self.include_gaze = include_gaze
@@ -527,6 +536,7 @@ class HeadNeRFNet(nn.Module):
         self._graphs = {}
         self._bg_cache = None
         self._maps_cache = {}
+        self._w10c_cache = {}
         # a (strict or not) load_state_dict replaces every weight: drop the packed copies
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_packed())
 
@@ -573,6 +583,8 @@ class HeadNeRFNet(nn.Module):
             self._pack_cache[k] = (None, buf)
         if self._bg_cache is not None:
             self._bg_cache = (None, self._bg_cache[1])
+        for k, (ver, buf) in list(self._w10c_cache.items()):
+            self._w10c_cache[k] = (None, buf)
         for k, ent in list(self._maps_cache.items()):
             self._maps_cache[k] = (None,) + tuple(ent[1:])
         self.neural_render.invalidate_packed()
@@ -584,6 +596,8 @@ class HeadNeRFNet(nn.Module):
         self.num_sample_fine = opt.num_sample_fine
         self.vp_n_freqs = 10
         self.include_input_for_vp_embeder = True
+        self.vd_n_freqs = 4
+        self.include_input_for_vd_embeder = True
         self.mlp_h_channel = opt.mlp_hidden_nchannels
         self.base_shape_code_dims = opt.iden_code_dims + opt.expr_code_dims
         self.base_appea_code_dims = opt.text_code_dims + opt.illu_code_dims
@@ -597,6 +611,9 @@ class HeadNeRFNet(nn.Module):
         if self.include_gaze:
             vp_channels += self.eye_gaze_dim
         vd_channels = self.base_appea_code_dims
+        if self.include_vd:
+            vd_channels += self.vd_n_freqs * 6 + 3
+            self.vd_encoder = Embedder(N_freqs=self.vd_n_freqs, include_input=self.include_input_for_vd_embeder)
         self.vp_encoder = Embedder(N_freqs=self.vp_n_freqs, include_input=self.include_input_for_vp_embeder)
         self.sample_func = GenSamplePoints(self.opt)
         self.fg_CD_predictor = MLPforNeRF(vp_channels=vp_channels, vd_channels=vd_channels, h_channel=self.mlp_h_channel,
@@ -616,13 +633,52 @@ class HeadNeRFNet(nn.Module):
     def _geom(self, batch, n_rays, xy, n_samples=None, z_planes_given=0, bg_is_hwc=0):
         return ops.make_geom(batch, n_rays, n_samples or self.num_sample_coarse, self.mlp_h_channel, self.featmap_nc,
                              self._shape_dim(), self.base_appea_code_dims, self.audio_dim, self.featmap_size,
-                             self.neural_render.n_blocks, self.opt.world_z1, self.opt.world_z2, xy.stride(), z_planes_given, bg_is_hwc)
+                             self.neural_render.n_blocks, self.opt.world_z1, self.opt.world_z2, xy.stride(), z_planes_given, bg_is_hwc,
+                             vd_dim=self._vd_dim())
+
+    def _vd_dim(self):
+        return self.vd_n_freqs * 6 + 3 if self.include_vd else 0
+
+    def _w10_compact(self, fine=False):
+        """include_vd: RGB_layer_1's weight WITHOUT its 27 view-direction columns, [192, 384 + appea] contiguous -- what the
+        library packs and folds; kept per parameter version in a buffer whose address does not change."""
+        layer = (self.fine_fg_CD_predictor if fine else self.fg_CD_predictor).RGB_layer_1
+        w = layer.w2d().detach()
+        ver = (w.data_ptr(), layer.weight._version)
+        hit = self._w10c_cache.get(fine)
+        if hit is None or hit[0] != ver or hit[1].device != w.device:
+            h, vd = self.mlp_h_channel, self._vd_dim()
+            buf = hit[1] if hit is not None and hit[1].device == w.device else torch.empty(w.shape[0], w.shape[1] - vd, dtype=torch.float32, device=w.device)
+            buf[:, :h].copy_(w[:, :h])
+            buf[:, h:].copy_(w[:, h + vd:])
+            hit = self._w10c_cache[fine] = (ver, buf)
+        return hit[1]
 
     def _mlp_params(self, fine=False):
         layers = (self.fine_fg_CD_predictor if fine else self.fg_CD_predictor).layers()
         ws = [m.w2d().detach() for m in layers]
         bs = [m.bias.detach() for m in layers]
+        if self.include_vd:
+            ws[10] = self._w10_compact(fine)
         return ops.mlp_params(ws, bs), ws, bs
+
+    def _vd_ray_bias(self, xy, batch_Rmats, batch_inv_inmats, fine=False):
+        """include_vd, differentiable: ray_bias [B, N_r, 192] = Embedder_4(ray direction) . RGB_layer_1.weight[:, 384:411]^T with
+        autograd (gradients reach the 27 weight columns and batch_Rmats).  The direction as GenSamplePoints builds it
+        (NetWorks/utils.py:149-153), the encoder's channel order as Embedder (:20-51).  A [B*N_r, 27] x [27, 192] product: plumbing
+        next to the sample-point work the kernels do; the inference path uses the HIP kernel (ops.ray_vd_bias)."""
+        B, _, n_r = xy.shape
+        ones = torch.ones(B, 1, n_r, dtype=torch.float32, device=xy.device)
+        d = batch_Rmats.float().bmm(batch_inv_inmats.float().bmm(torch.cat([xy, ones], dim=1)))  # [B,3,N_r]
+        d = d / torch.norm(d, dim=1, keepdim=True)
+        feats = [d]
+        for k in range(self.vd_n_freqs):
+            feats += [torch.sin(d * float(2 ** k)), torch.cos(d * float(2 ** k))]
+        pe = torch.cat(feats, dim=1)  # [B,27,N_r]
+        h = self.mlp_h_channel
+        w = (self.fine_fg_CD_predictor if fine else self.fg_CD_predictor).RGB_layer_1.weight
+        w_vd = w[:, h:h + self._vd_dim(), 0, 0]  # [192,27]
+        return torch.einsum("bjr,oj->bro", pe, w_vd).contiguous()
 
     def _packed(self, geom, precision, params, ws, bs, force=False):
         """Packed weights, re-packed whenever the optimizer (or a load) touched a parameter."""
@@ -656,12 +712,16 @@ class HeadNeRFNet(nn.Module):
         params, ws, bs = self._mlp_params(fine=z_planes is not None)
         packed = self._packed(geom, prec, params, ws, bs)
         audio = ops._f32c(audiostyle) if self.audio_dim > 0 else None
+        ray_bias = None
+        if self.include_vd:  # the view-direction columns of RGB_layer_1 as a per-ray bias (one small launch)
+            w10 = (self.fine_fg_CD_predictor if z_planes is not None else self.fg_CD_predictor).RGB_layer_1.w2d().detach()
+            ray_bias = ops.ray_vd_bias(geom, w10, xy, ops._f32c(batch_Rmats), ops._f32c(batch_inv_inmats))
         out = ops.render_fwd(geom, prec, packed, params, xy, ops._f32c(batch_Rmats), ops._f32c(batch_Tvecs).view(B, 3),
                              ops._f32c(batch_inv_inmats), ops._f32c(shape_code), ops._f32c(appea_code), audio,
                              None if t_rand is None else ops._f32c(t_rand),
                              self._bg_hwc() if want_merge else None,  # ray-major, cached per parameter version
                              want_depth=want_depth, want_weight=want_weight, want_merge=want_merge, merge_out=merge_out,
-                             want_fg=want_fg, weight_out=weight_out, ws=workspace)
+                             want_fg=want_fg, weight_out=weight_out, ws=workspace, ray_bias=ray_bias)
         return out
 
     def fine_planes(self, batch_xy, coarse_weight, batch_Tvecs, t_rand=None, fine_u=None, out=None):
@@ -751,7 +811,8 @@ class HeadNeRFNet(nn.Module):
         """Replay is used for plain mode="test" forwards (the reference's validation / fitting / sweep call shape,
         talker_trainer.py:1119, Utils/RenderUtils.py:120) on a GPU, unless switched off (use_graph=False or N3DT_GRAPH=0) or
         the bench's kernel-timing hook is active (its events belong to the launching call, which a replay never runs)."""
-        return (self.use_graph and not for_train and t_rand is None and batch_xy.is_cuda and not _lib.PROF_ACTIVE)
+        return (self.use_graph and not for_train and t_rand is None and batch_xy.is_cuda and not _lib.PROF_ACTIVE and
+                not self.include_vd)  # (include_vd allocates its per-ray bias per call: not recorded)
 
     def _param_signature(self):
         return tuple(p.data_ptr() for p in self.parameters())
@@ -872,6 +933,14 @@ class HeadNeRFNet(nn.Module):
             self._grad_arena.end_pass()  # (a backward that raised never told the arena that its pass was over)
         layers = self.fg_CD_predictor.layers()
         mlp = [m.weight for m in layers] + [m.bias for m in layers]
+        ray_bias = fine_ray_bias = None
+        if self.include_vd:
+            # RGB_layer_1 without its view-direction columns goes to the kernels (a differentiable cat: its gradient flows back
+            # into the parameter's other columns); the 27 columns act through the per-ray bias
+            h, vd = self.mlp_h_channel, self._vd_dim()
+            w10 = layers[10].weight
+            mlp[10] = torch.cat([w10[:, :h], w10[:, h + vd:]], dim=1)
+            ray_bias = self._vd_ray_bias(xy.detach(), batch_Rmats, batch_inv_inmats)
         audio = audiostyle if self.audio_dim > 0 else torch.zeros(B, 0, device=xy.device)
         n_pass = 2 if self.hier_sampling else 1
         nb = B * n_pass
@@ -880,7 +949,7 @@ class HeadNeRFNet(nn.Module):
         maps = torch.empty(nb + 1, fs, fs, C, dtype=torch.float32, device=xy.device)
         Kinv = ops._f32c(batch_inv_inmats)
         merge = _RenderFn.apply(self, geom, _Slot(maps[:B].view(B, n_r, C)), xy.detach(), Kinv, None if t_rand is None else ops._f32c(t_rand),
-                                batch_Rmats, batch_Tvecs, shape_code, appea_code, audio, self.neural_render.bg_featmap, *mlp)
+                                batch_Rmats, batch_Tvecs, shape_code, appea_code, audio, self.neural_render.bg_featmap, ray_bias, *mlp)
         merged = [merge]
         if self.hier_sampling:
             with torch.no_grad():
@@ -892,8 +961,12 @@ class HeadNeRFNet(nn.Module):
             gfine = self._geom(B, n_r, xy, n_samples=planes.shape[-1] - 1, z_planes_given=1)
             flayers = self.fine_fg_CD_predictor.layers()
             fmlp = [m.weight for m in flayers] + [m.bias for m in flayers]
+            if self.include_vd:
+                fw10 = flayers[10].weight
+                fmlp[10] = torch.cat([fw10[:, :h], fw10[:, h + vd:]], dim=1)
+                fine_ray_bias = self._vd_ray_bias(xy.detach(), batch_Rmats, batch_inv_inmats, fine=True)
             merged.append(_RenderFn.apply(self, gfine, _Slot(maps[B:nb].view(B, n_r, C)), xy.detach(), Kinv, planes, batch_Rmats, batch_Tvecs,
-                                          shape_code, appea_code, audio, self.neural_render.bg_featmap, *fmlp))
+                                          shape_code, appea_code, audio, self.neural_render.bg_featmap, fine_ray_bias, *fmlp))
         flat = []
         for m in self.neural_render._flat_modules():
             flat += [m.weight, m.bias]

@@ -51,10 +51,11 @@ WORKSPACE = _Workspace()
 
 
 def make_geom(batch, n_rays, n_samples, hidden, feat_nc, shape_dim, appea_dim, audio_dim, featmap_size, n_blocks,
-              world_z1, world_z2, xy_strides=(0, 0, 0), z_planes_given=0, bg_is_hwc=0):
+              world_z1, world_z2, xy_strides=(0, 0, 0), z_planes_given=0, bg_is_hwc=0, vd_dim=0):
     g = Geom()
     g.z_planes_given = int(z_planes_given)
     g.bg_is_hwc = int(bg_is_hwc)
+    g.vd_dim = int(vd_dim)  # include_vd: 27, and the render calls take a per-ray bias of RGB_layer_1
     g.batch, g.n_rays, g.n_samples = int(batch), int(n_rays), int(n_samples)
     g.hidden, g.feat_nc = int(hidden), int(feat_nc)
     g.shape_dim, g.appea_dim, g.audio_dim = int(shape_dim), int(appea_dim), int(audio_dim)
@@ -103,7 +104,7 @@ def render_workspace_bytes(geom, precision):
 
 
 def render_fwd(geom, precision, packed, params, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap,
-               want_depth=False, want_weight=False, want_merge=True, merge_out=None, want_fg=True, weight_out=None, ws=None):
+               want_depth=False, want_weight=False, want_merge=True, merge_out=None, want_fg=True, weight_out=None, ws=None, ray_bias=None):
     """a1..a7 fused.  Returns dict(fg_feat [B,Nr,C]?, bg_alpha [B,Nr]?, depth?, weight?, merge_feat?).
     With merge_out / weight_out / ws given (and want_fg, want_depth off) the call allocates nothing: hipGraph-capturable."""
     dev = xy.device
@@ -124,7 +125,7 @@ def render_fwd(geom, precision, packed, params, xy, R, T, Kinv, shape, appea, au
     assert ws.numel() >= ws_bytes
     rc = lib().n3dt_render_fwd(
         ctypes.byref(geom), precision, _ptr(packed), ctypes.byref(params), _ptr(xy), _ptr(R), _ptr(T), _ptr(Kinv),
-        _ptr(shape), _ptr(appea), _ptr(audio), _ptr(t_rand), _ptr(bg_featmap) if want_merge else None,
+        _ptr(shape), _ptr(appea), _ptr(audio), _ptr(t_rand), _ptr(bg_featmap) if want_merge else None, _ptr(ray_bias),
         _ptr(out["fg_feat"]), _ptr(out["bg_alpha"]), _ptr(out["depth"]), _ptr(out["weight"]), _ptr(out["merge_feat"]),
         _ptr(ws), ws_bytes, _stream())
     check(rc, "n3dt_render_fwd")
@@ -172,6 +173,28 @@ def embed(pts):
     pe = torch.empty((B, 63) + tuple(pts.shape[2:]), dtype=torch.float32, device=pts.device)
     check(lib().n3dt_embed(B, M, _ptr(pts), _ptr(pe), _stream()), "n3dt_embed")
     return pe
+
+
+def embed_freqs(pts, n_freqs):
+    """Embedder(N_freqs=n_freqs, include_input=True).forward: pts [B,3,...] -> [B, 3 + 6 n_freqs, ...]."""
+    pts = _f32c(pts)
+    B = pts.shape[0]
+    M = pts[0, 0].numel()
+    pe = torch.empty((B, 3 + 6 * n_freqs) + tuple(pts.shape[2:]), dtype=torch.float32, device=pts.device)
+    check(lib().n3dt_embed_freqs(B, M, int(n_freqs), _ptr(pts), _ptr(pe), _stream()), "n3dt_embed_freqs")
+    return pe
+
+
+def ray_vd_bias(geom, w_rgb1, xy, R, Kinv, out=None):
+    """include_vd: the per-ray bias of RGB_layer_1 from the ray direction (n3dt_ray_vd_bias).  w_rgb1: the layer's FULL 2-D
+    weight [192, 384 + 27 + appea_dim] (contiguous); its columns 384 .. 410 are read in place."""
+    assert w_rgb1.is_contiguous() and w_rgb1.dim() == 2 and w_rgb1.shape[0] == 192 and w_rgb1.shape[1] >= 384 + 27
+    B, Nr = geom.batch, geom.n_rays
+    rb = out if out is not None else torch.empty(B, Nr, 192, dtype=torch.float32, device=xy.device)
+    w_vd = ctypes.c_void_p(w_rgb1.data_ptr() + 384 * 4)
+    check(lib().n3dt_ray_vd_bias(ctypes.byref(geom), w_vd, int(w_rgb1.shape[1]), _ptr(xy), _ptr(R), _ptr(Kinv), _ptr(rb), _stream()),
+          "n3dt_ray_vd_bias")
+    return rb
 
 
 def mlp_points(geom, params, audio, embed_vps, embed_vds):
@@ -286,7 +309,7 @@ def _bytes_or_raise(n, what):
     return n
 
 
-def render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap, precision=0, merge_out=None):
+def render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape, appea, audio, t_rand, bg_featmap, precision=0, merge_out=None, ray_bias=None):
     """Forward with saved activations.  `packed` = pack_mlp(...) of the same precision.  Returns (out dict, saved buffer).
     merge_out: caller-owned [B, N_r, C] buffer for the merged map (a slice of the renderer's input batch)."""
     dev = xy.device
@@ -304,7 +327,7 @@ def render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape, appea, audio, 
     ws = WORKSPACE.get("train", wbytes, dev)
     check(lib().n3dt_render_train_fwd(
         ctypes.byref(geom), precision, _ptr(packed), ctypes.byref(params), _ptr(xy), _ptr(R), _ptr(T), _ptr(Kinv), _ptr(shape), _ptr(appea),
-        _ptr(audio), _ptr(t_rand), _ptr(bg_featmap), _ptr(out["fg_feat"]), _ptr(out["bg_alpha"]), None, _ptr(out["merge_feat"]),
+        _ptr(audio), _ptr(t_rand), _ptr(bg_featmap), _ptr(ray_bias), _ptr(out["fg_feat"]), _ptr(out["bg_alpha"]), None, _ptr(out["merge_feat"]),
         _ptr(saved), sbytes, _ptr(ws), wbytes, _stream()), "n3dt_render_train_fwd")
     return out, saved
 
@@ -312,7 +335,8 @@ def render_train_fwd(geom, packed, params, xy, R, T, Kinv, shape, appea, audio, 
 def render_bwd(geom, params, grads, shape, appea, audio, bg_featmap, d_merge, saved, cam=None, precision=0, d_bg=None, frozen=False):
     """Backward of render_train_fwd.  `grads` (MlpParams struct of zeroed tensors) is accumulated into.
     cam = (xy, R, T, Kinv, t_rand) requests camera gradients.
-    Returns (d_bg_featmap [C,Nr], d_shape, d_appea, d_audio, d_R, d_T)."""
+    Returns (d_bg_featmap [C,Nr], d_shape, d_appea, d_audio, d_R, d_T) -- and, with geom.vd_dim > 0 (include_vd), a seventh
+    entry d_ray_bias [B, N_r, 192]."""
     dev = d_merge.device
     B, Nr, C = geom.batch, geom.n_rays, geom.feat_nc
     if frozen:  # grads is None: no parameter gradient, no d_bg_featmap
@@ -332,13 +356,16 @@ def render_bwd(geom, params, grads, shape, appea, audio, bg_featmap, d_merge, sa
         d_R = torch.empty(B, 3, 3, dtype=torch.float32, device=dev)
         d_T = torch.empty(B, 3, dtype=torch.float32, device=dev)
         cam_ptrs = [_ptr(t) for t in cam]
+    d_ray = torch.empty(B, Nr, 192, dtype=torch.float32, device=dev) if geom.vd_dim > 0 else None
     wbytes = lib().n3dt_render_train_workspace_bytes(ctypes.byref(geom))
     ws = WORKSPACE.get("train", wbytes, dev)
     check(lib().n3dt_render_bwd(
         ctypes.byref(geom), precision, ctypes.byref(params), None if grads is None else ctypes.byref(grads), _ptr(shape), _ptr(appea), _ptr(audio),
         _ptr(bg_featmap),
-        _ptr(d_merge), None, None, _ptr(saved), saved.numel(), _ptr(d_bg), _ptr(d_shape), _ptr(d_appea), _ptr(d_audio),
+        _ptr(d_merge), None, None, _ptr(saved), saved.numel(), _ptr(d_bg), _ptr(d_shape), _ptr(d_appea), _ptr(d_audio), _ptr(d_ray),
         *cam_ptrs, _ptr(d_R), _ptr(d_T), _ptr(ws), wbytes, _stream()), "n3dt_render_bwd")
+    if d_ray is not None:
+        return d_bg, d_shape, d_appea, d_audio, d_R, d_T, d_ray
     return d_bg, d_shape, d_appea, d_audio, d_R, d_T
 
 

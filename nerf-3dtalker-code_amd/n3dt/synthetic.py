@@ -29,8 +29,9 @@ def n_blocks(opt):
     return int(math.log2(opt.pred_img_size) - math.log2(opt.featmap_size))
 
 
-def mlp_dims(opt, include_gaze=False, eye_gaze_dim=2, audio_dim=64):
-    """Channel bookkeeping of the latent-conditioned MLP."""
+def mlp_dims(opt, include_gaze=False, eye_gaze_dim=2, audio_dim=64, include_vd=False):
+    """Channel bookkeeping of the latent-conditioned MLP.  include_vd: RGB_layer_1 takes 27 more channels (the
+    4-frequency encoding of the ray direction, NetWorks/HeadNeRFNet.py:56-63), between RGB_layer_0's output and the appearance code."""
     shape_dim = opt.iden_code_dims + opt.expr_code_dims + (eye_gaze_dim if include_gaze else 0)
     appea_dim = opt.text_code_dims + opt.illu_code_dims
     vp = PE_DIM + shape_dim
@@ -43,17 +44,17 @@ def mlp_dims(opt, include_gaze=False, eye_gaze_dim=2, audio_dim=64):
         "vp": vp,
         "in0": vp + audio_dim,
         "in5": vp + opt.mlp_hidden_nchannels,
-        "in_rgb1": opt.mlp_hidden_nchannels + appea_dim,
+        "in_rgb1": opt.mlp_hidden_nchannels + (27 if include_vd else 0) + appea_dim,
     }
 
 
-def param_specs(opt, include_gaze=False, eye_gaze_dim=2, audio_dim=64, hier_sampling=False):
+def param_specs(opt, include_gaze=False, eye_gaze_dim=2, audio_dim=64, hier_sampling=False, include_vd=False):
     """Ordered name -> (shape, init_kind, is_buffer).
 
     init_kind: "xavier" | "default_w" | "default_b" | "zero" | "ones" | "blur"
     Key names are the reference module's state-dict keys.
     """
-    d = mlp_dims(opt, include_gaze, eye_gaze_dim, audio_dim)
+    d = mlp_dims(opt, include_gaze, eye_gaze_dim, audio_dim, include_vd)
     H, C = d["H"], d["C"]
     specs = OrderedDict()
 
@@ -119,7 +120,7 @@ def init_tensor(shape, kind, gen, fan_in_of_weight=None):
     return (torch.rand(shape, generator=gen) * 2.0 - 1.0) * a
 
 
-def make_state_dict(opt, seed=0, include_gaze=False, eye_gaze_dim=2, audio_dim=64, bg_noise=0.0, hier_sampling=False):
+def make_state_dict(opt, seed=0, include_gaze=False, eye_gaze_dim=2, audio_dim=64, bg_noise=0.0, hier_sampling=False, include_vd=False):
     """Seeded random weights with the reference's per-layer init distributions.
 
     bg_noise > 0 perturbs the learned background feature map away from its
@@ -129,7 +130,7 @@ def make_state_dict(opt, seed=0, include_gaze=False, eye_gaze_dim=2, audio_dim=6
     sd = OrderedDict()
     last_fan_in = None
     fine = OrderedDict()
-    for name, (shape, kind, _buf) in param_specs(opt, include_gaze, eye_gaze_dim, audio_dim, hier_sampling).items():
+    for name, (shape, kind, _buf) in param_specs(opt, include_gaze, eye_gaze_dim, audio_dim, hier_sampling, include_vd).items():
         if name.startswith("fine_"):
             fine[name] = (shape, kind)
             continue

@@ -211,7 +211,25 @@ void orc_embed(int B, long M, const float* pts, float* pe) {
 
 typedef struct {
     int H, C, shape_dim, appea_dim, audio_dim;
+    int vd_dim; /* include_vd: 27 view-direction channels between RGB_layer_0's output and the appearance code, else 0
+                   (NetWorks/HeadNeRFNet.py:56-63,86; models.py:80) */
 } orc_dims;
+
+/* vd_encoder: Embedder(N_freqs=4, include_input=True) of a ray direction (HeadNeRFNet.py:30-31,61,141-142; utils.py:20-51) */
+#define VD_FREQS 4
+#define VD_DIM (3 + 6 * VD_FREQS)
+static inline void embed_dir(const float d[3], float* out, size_t stride) {
+    for (int i = 0; i < 3; ++i) out[(size_t)i * stride] = d[i];
+    float f = 1.0f;
+    for (int k = 0; k < VD_FREQS; ++k) {
+        for (int i = 0; i < 3; ++i) {
+            float a = d[i] * f;
+            out[(size_t)(3 + 6 * k + i) * stride] = sinf(a);
+            out[(size_t)(3 + 6 * k + 3 + i) * stride] = cosf(a);
+        }
+        f *= 2.0f;
+    }
+}
 
 static void dense(const float* W, const float* bias, int cin, int cout, const float* x, float* y, int relu) {
     for (int o = 0; o < cout; ++o) {
@@ -232,8 +250,9 @@ static void dense(const float* W, const float* bias, int cin, int cout, const fl
 
 /* pe_blk: [63][NB]; outputs rgb_blk [C][NB], dens_blk [NB].  scratch >= (in5 + 2H + in_rgb1) * NB floats. */
 static void mlp_block(const orc_dims* dm, const float* const* w, const float* pe_blk, const float* shape,
-                      const float* appea, const float* audio, float* rgb_blk, float* dens_blk, float* scratch) {
-    int H = dm->H, vp = PE_DIM + dm->shape_dim, in0 = vp + dm->audio_dim, in5 = vp + H, inr = H + dm->appea_dim;
+                      const float* appea, const float* audio, const float* vd_blk /* [vd_dim][NB] or NULL */, float* rgb_blk,
+                      float* dens_blk, float* scratch) {
+    int H = dm->H, vp = PE_DIM + dm->shape_dim, in0 = vp + dm->audio_dim, in5 = vp + H, inr = H + dm->vd_dim + dm->appea_dim;
     float* x0 = scratch;                        /* [max(in0,in5)][NB], rows 0..vp-1 = [PE | shape] */
     int xrows = in0 > in5 ? in0 : in5;
     float* ha = x0 + (size_t)xrows * NB;        /* [H][NB] */
@@ -262,28 +281,39 @@ static void mlp_block(const orc_dims* dm, const float* const* w, const float* pe
     }
     /* feature head (models.py:79-82): RGB_layer_0 has no activation; cat appea; relu after RGB_layer_1 */
     dense(w[18], w[19], H, H, cur, xr, 0);
-    for (int i = 0; i < dm->appea_dim; ++i) for (int p = 0; p < NB; ++p) xr[(size_t)(H + i) * NB + p] = appea[i];
+    /* include_vd: cat([x, embed_vds]) with embed_vds = cat([vd_embed, appea]) (HeadNeRFNet.py:86, models.py:80) */
+    if (dm->vd_dim) memcpy(xr + (size_t)H * NB, vd_blk, sizeof(float) * (size_t)dm->vd_dim * NB);
+    for (int i = 0; i < dm->appea_dim; ++i) for (int p = 0; p < NB; ++p) xr[(size_t)(H + dm->vd_dim + i) * NB + p] = appea[i];
     dense(w[20], w[21], inr, H / 2, xr, nxt, 1);
     dense(w[22], w[23], H / 2, dm->C, nxt, rgb_blk, 0); /* C != 3: no sigmoid (models.py:85-86) */
 }
 
 static size_t mlp_scratch_floats(const orc_dims* dm) {
-    int H = dm->H, vp = PE_DIM + dm->shape_dim, in0 = vp + dm->audio_dim, in5 = vp + H, inr = H + dm->appea_dim;
+    int H = dm->H, vp = PE_DIM + dm->shape_dim, in0 = vp + dm->audio_dim, in5 = vp + H, inr = H + dm->vd_dim + dm->appea_dim;
     int xrows = in0 > in5 ? in0 : in5;
     return (size_t)(xrows + 2 * H + inr) * NB;
 }
 
 /* pe [B,63,M] -> rgb [B,C,M], density [B,M] */
+void orc_mlp_vd(int B, long M, int H, int C, int shape_dim, int appea_dim, int audio_dim, int vd_dim, const float* const* w,
+                const float* pe, const float* shape, const float* appea, const float* audio, const float* vd /* [B,vd_dim,M] */,
+                float* rgb, float* density);
 void orc_mlp(int B, long M, int H, int C, int shape_dim, int appea_dim, int audio_dim, const float* const* w,
              const float* pe, const float* shape, const float* appea, const float* audio, float* rgb, float* density) {
-    orc_dims dm = {H, C, shape_dim, appea_dim, audio_dim};
+    orc_mlp_vd(B, M, H, C, shape_dim, appea_dim, audio_dim, 0, w, pe, shape, appea, audio, NULL, rgb, density);
+}
+void orc_mlp_vd(int B, long M, int H, int C, int shape_dim, int appea_dim, int audio_dim, int vd_dim, const float* const* w,
+                const float* pe, const float* shape, const float* appea, const float* audio, const float* vd, float* rgb,
+                float* density) {
+    orc_dims dm = {H, C, shape_dim, appea_dim, audio_dim, vd_dim};
     long nblk = (M + NB - 1) / NB;
 #pragma omp parallel
     {
-        float* scratch = (float*)malloc(sizeof(float) * (mlp_scratch_floats(&dm) + (size_t)(PE_DIM + C + 1) * NB));
+        float* scratch = (float*)malloc(sizeof(float) * (mlp_scratch_floats(&dm) + (size_t)(PE_DIM + C + 1 + VD_DIM) * NB));
         float* pe_blk = scratch + mlp_scratch_floats(&dm);
         float* rgb_blk = pe_blk + (size_t)PE_DIM * NB;
         float* dens_blk = rgb_blk + (size_t)C * NB;
+        float* vd_blk = dens_blk + NB;
 #pragma omp for collapse(2) schedule(dynamic, 4)
         for (int b = 0; b < B; ++b)
             for (long k = 0; k < nblk; ++k) {
@@ -292,8 +322,11 @@ void orc_mlp(int B, long M, int H, int C, int shape_dim, int appea_dim, int audi
                 for (int c = 0; c < PE_DIM; ++c)
                     for (int p = 0; p < NB; ++p)
                         pe_blk[(size_t)c * NB + p] = p < n ? pe[((size_t)b * PE_DIM + c) * M + m0 + p] : 0.0f;
+                for (int c = 0; c < vd_dim; ++c)
+                    for (int p = 0; p < NB; ++p)
+                        vd_blk[(size_t)c * NB + p] = p < n ? vd[((size_t)b * vd_dim + c) * M + m0 + p] : 0.0f;
                 mlp_block(&dm, w, pe_blk, shape + (size_t)b * shape_dim, appea + (size_t)b * appea_dim,
-                          audio_dim ? audio + (size_t)b * audio_dim : NULL, rgb_blk, dens_blk, scratch);
+                          audio_dim ? audio + (size_t)b * audio_dim : NULL, vd_dim ? vd_blk : NULL, rgb_blk, dens_blk, scratch);
                 for (int c = 0; c < C; ++c)
                     for (int p = 0; p < n; ++p) rgb[((size_t)b * C + c) * M + m0 + p] = rgb_blk[(size_t)c * NB + p];
                 for (int p = 0; p < n; ++p) density[(size_t)b * M + m0 + p] = dens_blk[p];
@@ -479,23 +512,39 @@ void orc_blur(int c, int h, int w, const float* x, float* y) { blur3(c, h, w, x,
  * outputs: fg_feat [B,C,Nr] (nullable), bg_alpha [B,Nr] (nullable), merge_img [B,3,P,P], bg_img [1,3,P,P]
  * Requires Ns <= NB (64) per block; longer rays are processed in NB-sample blocks.
  * ------------------------------------------------------------------------------------- */
+void orc_forward_vd(int B, int Nr, int Ns, int fs, int n_blocks, int H, int C, int shape_dim, int appea_dim, int audio_dim, int vd_dim,
+                    const float* const* mlp_w, const float* const* nr_w, const float* bg_featmap, const float* xy, const float* R,
+                    const float* T, const float* Kinv, float world_z1, float world_z2, const float* t_rand, const float* shape,
+                    const float* appea, const float* audio, float* fg_feat_out, float* bg_alpha_out, float* merge_img, float* bg_img,
+                    int skip_neural_render);
 void orc_forward(int B, int Nr, int Ns, int fs, int n_blocks, int H, int C, int shape_dim, int appea_dim, int audio_dim,
                  const float* const* mlp_w, const float* const* nr_w, const float* bg_featmap /* [C,fs,fs] */,
                  const float* xy, const float* R, const float* T, const float* Kinv, float world_z1, float world_z2,
                  const float* t_rand, const float* shape, const float* appea, const float* audio,
                  float* fg_feat_out, float* bg_alpha_out, float* merge_img, float* bg_img, int skip_neural_render) {
-    orc_dims dm = {H, C, shape_dim, appea_dim, audio_dim};
+    orc_forward_vd(B, Nr, Ns, fs, n_blocks, H, C, shape_dim, appea_dim, audio_dim, 0, mlp_w, nr_w, bg_featmap, xy, R, T, Kinv, world_z1,
+                   world_z2, t_rand, shape, appea, audio, fg_feat_out, bg_alpha_out, merge_img, bg_img, skip_neural_render);
+}
+/* vd_dim = 27: include_vd=True (the view direction of the ray, encoded, joins RGB_layer_1's input at every sample:
+ * HeadNeRFNet.py:141-142 `vd_encoder(fg_dirs)`, fg_dirs = the ray direction expanded over the samples, utils.py:84) */
+void orc_forward_vd(int B, int Nr, int Ns, int fs, int n_blocks, int H, int C, int shape_dim, int appea_dim, int audio_dim, int vd_dim,
+                    const float* const* mlp_w, const float* const* nr_w, const float* bg_featmap /* [C,fs,fs] */,
+                    const float* xy, const float* R, const float* T, const float* Kinv, float world_z1, float world_z2,
+                    const float* t_rand, const float* shape, const float* appea, const float* audio,
+                    float* fg_feat_out, float* bg_alpha_out, float* merge_img, float* bg_img, int skip_neural_render) {
+    orc_dims dm = {H, C, shape_dim, appea_dim, audio_dim, vd_dim};
     float* fg = fg_feat_out ? fg_feat_out : (float*)malloc(sizeof(float) * (size_t)B * C * Nr);
     float* ba = bg_alpha_out ? bg_alpha_out : (float*)malloc(sizeof(float) * (size_t)B * Nr);
     int nblk = (Ns + NB - 1) / NB;
 #pragma omp parallel
     {
         size_t sf = mlp_scratch_floats(&dm);
-        float* scratch = (float*)malloc(sizeof(float) * (sf + (size_t)(PE_DIM + C + 1) * NB + (size_t)(C + 3) * nblk * NB));
+        float* scratch = (float*)malloc(sizeof(float) * (sf + (size_t)(PE_DIM + C + 1 + VD_DIM) * NB + (size_t)(C + 3) * nblk * NB));
         float* pe_blk = scratch + sf;
         float* rgb_blk = pe_blk + (size_t)PE_DIM * NB;
         float* dens_blk = rgb_blk + (size_t)C * NB;
-        float* ray_rgb = dens_blk + NB;                       /* [C][nblk*NB] */
+        float* vd_blk = dens_blk + NB;                        /* [VD_DIM][NB]: the ray's encoded direction at every sample */
+        float* ray_rgb = vd_blk + (size_t)VD_DIM * NB;        /* [C][nblk*NB] */
         float* ray_dens = ray_rgb + (size_t)C * nblk * NB;
         float* ray_dist = ray_dens + (size_t)nblk * NB;
         float* ray_w = ray_dist + (size_t)nblk * NB;
@@ -508,6 +557,8 @@ void orc_forward(int B, int Nr, int Ns, int fs, int n_blocks, int H, int C, int 
                 float rz1 = Tb[2] - world_z1, rz2 = Tb[2] - world_z2;
                 const float* tr = t_rand ? t_rand + ((size_t)b * Nr + r) * (Ns + 1) : NULL;
                 int W = nblk * NB;
+                if (vd_dim)
+                    for (int p = 0; p < NB; ++p) embed_dir(d, vd_blk + p, NB);
                 for (int k = 0; k < nblk; ++k) {
                     for (int p = 0; p < NB; ++p) {
                         int s = k * NB + p;
@@ -520,7 +571,7 @@ void orc_forward(int B, int Nr, int Ns, int fs, int n_blocks, int H, int C, int 
                         embed_point(pt, pe_blk + p, NB);
                     }
                     mlp_block(&dm, mlp_w, pe_blk, shape + (size_t)b * shape_dim, appea + (size_t)b * appea_dim,
-                              audio_dim ? audio + (size_t)b * audio_dim : NULL, rgb_blk, dens_blk, scratch);
+                              audio_dim ? audio + (size_t)b * audio_dim : NULL, vd_dim ? vd_blk : NULL, rgb_blk, dens_blk, scratch);
                     for (int c = 0; c < C; ++c) memcpy(ray_rgb + (size_t)c * W + k * NB, rgb_blk + (size_t)c * NB, sizeof(float) * NB);
                     memcpy(ray_dens + k * NB, dens_blk, sizeof(float) * NB);
                 }

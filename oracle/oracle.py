@@ -122,7 +122,8 @@ def embed(pts):
     return pe
 
 
-def mlp(sd, pe, shape, appea, audio, C=256, H=384, prefix="fg_CD_predictor."):
+def mlp(sd, pe, shape, appea, audio, C=256, H=384, prefix="fg_CD_predictor.", vd=None):
+    """vd: [B,27,...] the encoded view directions (include_vd=True), else None."""
     pe, shape, appea = _f32(pe), _f32(shape), _f32(appea)
     audio = _f32(audio) if audio is not None and np.asarray(audio).size else None
     B = pe.shape[0]
@@ -130,8 +131,9 @@ def mlp(sd, pe, shape, appea, audio, C=256, H=384, prefix="fg_CD_predictor."):
     wl, keep = _ptr_array(mlp_weight_list(sd, prefix))
     rgb = np.empty((B, C) + pe.shape[2:], np.float32)
     dens = np.empty((B, 1) + pe.shape[2:], np.float32)
-    lib().orc_mlp(B, ctypes.c_long(M), H, C, shape.shape[1], appea.shape[1], 0 if audio is None else audio.shape[1], wl,
-                  _p(pe), _p(shape), _p(appea), _p(audio), _p(rgb), _p(dens))
+    vd = _f32(vd) if vd is not None else None
+    lib().orc_mlp_vd(B, ctypes.c_long(M), H, C, shape.shape[1], appea.shape[1], 0 if audio is None else audio.shape[1],
+                     0 if vd is None else vd.shape[1], wl, _p(pe), _p(shape), _p(appea), _p(audio), _p(vd), _p(rgb), _p(dens))
     return rgb, dens
 
 
@@ -169,8 +171,9 @@ def blur(x):
     return y
 
 
-def forward(sd, opt, inp, t_rand=None, skip_neural_render=False):
-    """Whole path on the CPU.  inp: dict with the reference's kwarg names (numpy or torch)."""
+def forward(sd, opt, inp, t_rand=None, skip_neural_render=False, include_vd=False):
+    """Whole path on the CPU.  inp: dict with the reference's kwarg names (numpy or torch).  include_vd: the module built with
+    include_vd=True (RGB_layer_1 takes the 27-channel encoding of the ray direction, NetWorks/HeadNeRFNet.py:56-63)."""
     import math
     xy = _f32(_np(inp["batch_xy"]))
     B, _, Nr = xy.shape
@@ -189,8 +192,8 @@ def forward(sd, opt, inp, t_rand=None, skip_neural_render=False):
     ba = np.empty((B, 1, Nr), np.float32)
     merge_img = np.empty((B, 3, P, P), np.float32)
     bg_img = np.empty((1, 3, P, P), np.float32)
-    lib().orc_forward(B, Nr, opt.num_sample_coarse, fs, nb, H, C, shape.shape[1], appea.shape[1],
-                      0 if audio is None else audio.shape[1], mw, nw, _p(bgf), _p(xy), _p(R), _p(T), _p(K),
+    lib().orc_forward_vd(B, Nr, opt.num_sample_coarse, fs, nb, H, C, shape.shape[1], appea.shape[1],
+                      0 if audio is None else audio.shape[1], 27 if include_vd else 0, mw, nw, _p(bgf), _p(xy), _p(R), _p(T), _p(K),
                       ctypes.c_float(opt.world_z1), ctypes.c_float(opt.world_z2), _p(tr), _p(shape), _p(appea), _p(audio),
                       _p(fg), _p(ba), _p(merge_img), _p(bg_img), int(skip_neural_render))
     return {"fg_feat": fg, "bg_alpha": ba, "merge_img": merge_img, "bg_img": bg_img}

@@ -55,7 +55,7 @@ def synthetic_case(m, **kw):
         sd = syn.contrast_state_dict(opt, seed=m.get("weights_seed", 0))
     else:
         sd = syn.make_state_dict(opt, seed=m.get("weights_seed", 0), bg_noise=m.get("bg_noise", 0.0),
-                                 hier_sampling=bool(m.get("hier_sampling", False)), **kw)
+                                 hier_sampling=bool(m.get("hier_sampling", False)), include_vd=bool(m.get("include_vd", False)), **kw)
     cs = syn.state_dict_checksum(sd)
     ref = m.get("weights_checksum")
     if ref is not None and not kw:

@@ -55,7 +55,7 @@ def feats(net, d, t_rand=None, **kw):
 
 def test_native_library_is_loaded():
     from n3dt import _lib
-    assert _lib.lib().n3dt_abi_version() == 4
+    assert _lib.lib().n3dt_abi_version() == 5
     with open("/proc/self/maps") as f:
         assert "libn3dt.so" in f.read()
 

@@ -168,3 +168,128 @@ def test_a_non_finite_feature_stays_local_in_the_renderer(precision):
     allowed[max(0, y0 - grow):y1 + grow + 1, max(0, x0 - grow):x1 + grow + 1] = True
     assert not (bad & ~allowed).any(), "NaN reached pixels far from the reference's patch: %d" % int((bad & ~allowed).sum())
     assert np.array_equal(dirty[0][:, ~bad], clean[0][:, ~bad]), "finite pixels changed"
+
+
+# ---- include_vd=True (NetWorks/HeadNeRFNet.py:56-63,86,141-142) ------------------------------------------------------------
+VD_RGB_TOL = {"fp32": 1e-4, "bf16": 1e-3, "fp16": 5e-4, "bf16x3": 1e-4}
+VD_FEAT_TOL = {"fp32": 2e-5, "bf16": 5e-3, "fp16": 1e-3, "bf16x3": 1e-4}
+
+
+def _vd_setup(name, precision="fp32", train_precision="fp32"):
+    from conftest import load_golden, synthetic_case
+    from n3dt import HeadNeRFNet, synthetic as syn
+    g, m = load_golden(name)
+    opt, sd, inp = synthetic_case(m)
+    net = HeadNeRFNet(opt, include_vd=True, hier_sampling=False, precision=precision, train_precision=train_precision).to(dev())
+    net.load_state_dict(sd, strict=True)
+    t_rand = None
+    if m["mode"] == "train":
+        t_rand = syn.stratified_noise(m["batch"], opt.featmap_size ** 2, opt.num_sample_coarse, m["t_rand_seed"]).to(dev())
+    return g, m, opt, sd, net, to_dev(inp), t_rand
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16", "bf16x3"])
+@pytest.mark.parametrize("name", ["vd_test", "vd_train"])
+def test_include_vd_render_against_the_reference(name, precision):
+    """The module built with include_vd=True against the REFERENCE module built the same way (fixtures vd_*): the 27 view-direction
+    channels of RGB_layer_1 enter as a per-ray bias (one 27-wide product per ray, csrc/nerf_aux.hip: ray_vd_bias_kernel), in the
+    exact-fp32 kernel and the three MFMA kernels."""
+    g, m, opt, sd, net, d, t_rand = _vd_setup(name, precision)
+    with torch.no_grad():
+        f = net.render_features(d["batch_xy"], d["audiostyle"], d["shape_code"], d["appea_code"], d["batch_Rmats"], d["batch_Tvecs"],
+                                d["batch_inv_inmats"], t_rand=t_rand)
+        out = net(m["mode"], d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+                  d["batch_Tvecs"], d["batch_inv_inmats"], t_rand=t_rand)["coarse_dict"]
+    np.testing.assert_allclose(f["fg_feat"].permute(0, 2, 1).cpu().numpy(), g["fg_feat"], atol=VD_FEAT_TOL[precision])
+    np.testing.assert_allclose(f["bg_alpha"].cpu().numpy()[:, None], g["bg_alpha"], atol=VD_FEAT_TOL[precision])
+    assert np.abs(out["merge_img"].cpu().numpy() - g["merge_img"]).max() <= VD_RGB_TOL[precision]
+    # the stand-alone seams: vd_encoder(dirs) and fg_CD_predictor(audio, embed_vps, embed_vds) with the 154-channel embed_vds
+    if precision == "fp32":
+        smp = net.sample_func(d["batch_xy"], d["batch_Rmats"], d["batch_Tvecs"], d["batch_inv_inmats"], m["mode"] == "train", t_rand=t_rand)
+        vd = net.vd_encoder(smp["dirs"])
+        np.testing.assert_allclose(vd[:, :, :, 0].cpu().numpy(), g["vd_embed_ray"], atol=1e-6)
+        ns = opt.num_sample_coarse
+        n_r = smp["pts"].shape[2]
+        vp = torch.cat([net.vp_encoder(smp["pts"]), d["shape_code"][:, :, None, None].expand(-1, -1, n_r, ns)], dim=1)
+        vds = torch.cat([vd, d["appea_code"][:, :, None, None].expand(-1, -1, n_r, ns)], dim=1)
+        rgb, dens = net.fg_CD_predictor(d["audiostyle"][:, :, None, None].expand(-1, -1, n_r, ns), vp, vds)
+        np.testing.assert_allclose(rgb.cpu().numpy(), g["feat"], atol=2e-4)
+
+
+def test_include_vd_mid_size_against_the_oracle():
+    """fs 16, 48 samples (a ragged second block), B = 3, the hierarchical pass off: every precision against the CPU oracle."""
+    from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
+    from oracle import oracle as orc
+    opt = BaseOptions({"featmap_size": 16, "featmap_nc": 256, "pred_img_size": 64, "num_sample_coarse": 48})
+    sd = syn.make_state_dict(opt, seed=4, bg_noise=0.1, include_vd=True)
+    inp = syn.frame_inputs(opt, 3)
+    ref = orc.forward(sd, opt, inp, include_vd=True)
+    d = to_dev(inp)
+    for precision in ("fp32", "bf16", "fp16", "bf16x3"):
+        net = HeadNeRFNet(opt, include_vd=True, hier_sampling=False, precision=precision).to(dev())
+        net.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            out = net("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+                      d["batch_Tvecs"], d["batch_inv_inmats"])["coarse_dict"]
+        assert np.abs(out["merge_img"].cpu().numpy() - ref["merge_img"]).max() <= VD_RGB_TOL[precision], precision
+
+
+@pytest.mark.parametrize("name", ["vd_test", "vd_train"])
+def test_include_vd_gradients_match_the_reference_autograd(name):
+    """Exact-fp32 training path with include_vd=True against the reference's autograd: every parameter (the 27 view-direction
+    columns of RGB_layer_1 in full), the latent codes and the cameras -- the rotation's gradient now has a second route, through
+    the ray direction into the encoder -- and one Adam step."""
+    from n3dt.train import data_losses, disk_mask
+    g, m, opt, sd, net, d, t_rand = _vd_setup(name)
+    for k in ("audiostyle", "shape_code", "appea_code", "batch_Rmats", "batch_Tvecs"):
+        d[k] = d[k].clone().requires_grad_(True)
+    out = net(m["mode"], d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+              d["batch_Tvecs"], d["batch_inv_inmats"], t_rand=t_rand)["coarse_dict"]
+    terms = data_losses(out, torch.full_like(out["merge_img"], 0.5), disk_mask(m["batch"], opt.pred_img_size).to(dev()))
+    np.testing.assert_allclose([float(terms[k].detach()) for k in ("bg_loss", "head_loss", "nonhead_loss")], g["loss_terms"], atol=1e-6)
+    (terms["bg_loss"] + terms["head_loss"] + terms["nonhead_loss"]).backward()
+    for k in ("audiostyle", "shape_code", "appea_code", "batch_Rmats", "batch_Tvecs"):
+        ref = g["grad_in." + k]
+        tol = 5e-2 if k.startswith("batch_") else 2e-2
+        assert np.abs(d[k].grad.cpu().numpy() - ref).max() <= tol * np.abs(ref).max(), k
+    for pname, p in net.named_parameters():
+        assert p.grad is not None, pname
+        idx, val = g["grad_p.%s.idx" % pname], g["grad_p.%s.val" % pname]
+        got = p.grad.reshape(-1)[torch.from_numpy(idx).to(dev())].cpu().numpy()
+        assert np.abs(got - val).max() <= 2e-2 * (np.abs(val).max() + 1e-12), pname
+    gv = net.fg_CD_predictor.RGB_layer_1.weight.grad[:, 384:411, 0, 0].cpu().numpy()
+    assert np.abs(gv - g["grad_vd_columns"]).max() <= 2e-2 * np.abs(g["grad_vd_columns"]).max()
+    assert np.abs(g["grad_vd_columns"]).max() > 0
+
+
+def test_include_vd_bf16_training_path_against_the_fp32_path():
+    """The fused bf16 training path with include_vd=True: its per-ray bias rides in the merged RGB stage, its gradient is the
+    per-ray sum of that stage's dZ tiles (dz_ray_rowsum_kernel).  Against the exact path on the same inputs, the usual bf16 band."""
+    from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
+    from n3dt.train import data_losses, disk_mask
+    opt = BaseOptions({"featmap_size": 16, "featmap_nc": 256, "pred_img_size": 64, "num_sample_coarse": 40})
+    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1, include_vd=True)
+    B = 2
+    t_rand = syn.stratified_noise(B, 256, 40, 7).to(dev())
+
+    def grads(tp):
+        net = HeadNeRFNet(opt, include_vd=True, hier_sampling=False, train_precision=tp).to(dev())
+        net.load_state_dict(sd, strict=True)
+        net.neural_render.train_precision = "fp32"
+        d = to_dev(syn.frame_inputs(opt, B))
+        d["batch_Rmats"] = d["batch_Rmats"].clone().requires_grad_(True)
+        out = net("train", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+                  d["batch_Tvecs"], d["batch_inv_inmats"], t_rand=t_rand)["coarse_dict"]
+        t = data_losses(out, torch.full_like(out["merge_img"], 0.5), disk_mask(B, opt.pred_img_size).to(dev()))
+        (t["bg_loss"] + t["head_loss"] + t["nonhead_loss"]).backward()
+        gd = {n: p.grad.detach().clone() for n, p in net.named_parameters() if n.startswith("fg_CD_predictor")}
+        return out["merge_img"].detach(), gd
+    img32, g32 = grads("fp32")
+    img16, g16 = grads("bf16")
+    assert float((img32 - img16).abs().max()) <= 2e-3
+    for k in g32:
+        a, b = g32[k].double().flatten(), g16[k].double().flatten()
+        assert float((a - b).abs().max()) <= 5e-2 * float(a.abs().max()) + 1e-12, k
+        assert float((a * b).sum() / (a.norm() * b.norm() + 1e-30)) >= 0.995, k
+    vd32 = g32["fg_CD_predictor.RGB_layer_1.weight"][:, 384:411]
+    assert float(vd32.abs().max()) > 0

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), "libn3dt.so does not export %s" % name
-    assert L.n3dt_abi_version() == 4
+    assert L.n3dt_abi_version() == 5
 
 
 def test_geometry_validation_without_a_gpu():
@@ -80,8 +80,9 @@ def test_constructor_variants_and_rejections():
     from n3dt import synthetic as syn
     assert set(h.state_dict().keys()) == set(syn.param_specs(opt, hier_sampling=True).keys())
     assert h.state_dict()["fine_fg_CD_predictor.RGB_layer_1.weight"].shape == (192, 511, 1, 1)
-    with pytest.raises(NotImplementedError):
-        HeadNeRFNet(opt, True, False)  # include_vd: never used by the reference's callers
+    v = HeadNeRFNet(opt, True, False)  # include_vd: 27 view-direction channels join RGB_layer_1's input (HeadNeRFNet.py:56-63)
+    assert v.state_dict()["fg_CD_predictor.RGB_layer_1.weight"].shape == (192, 384 + 27 + 127, 1, 1)
+    assert set(v.state_dict().keys()) == set(syn.param_specs(opt, include_vd=True).keys()) and hasattr(v, "vd_encoder")
     opt.bg_type = "green"
     with pytest.raises(ValueError):
         HeadNeRFNet(opt, False, False)

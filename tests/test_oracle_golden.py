@@ -197,3 +197,31 @@ def test_committed_fixture_is_what_the_reference_emits_today(tmp_path):
     mo = json.load(open(os.path.join(GOLDEN, "tiny_test.json")))
     mn.pop("reference", None), mo.pop("reference", None)  # (names the torch build that ran the generator)
     assert mn == mo
+
+
+@pytest.mark.parametrize("name", ["vd_test", "vd_train"])
+def test_forward_include_vd(name):
+    """include_vd=True (NetWorks/HeadNeRFNet.py:56-63,86,141-142): the oracle's view-direction encoder, the 538-wide RGB_layer_1
+    and the whole forward against what the reference module built with include_vd=True emits."""
+    g, m = load_golden(name)
+    opt, sd, inp = synthetic_case(m)
+    assert tuple(sd["fg_CD_predictor.RGB_layer_1.weight"].shape) == (192, 384 + 27 + 127, 1, 1)
+    t_rand = None
+    if m["mode"] == "train":
+        from n3dt import synthetic as syn
+        t_rand = syn.stratified_noise(m["batch"], opt.featmap_size ** 2, opt.num_sample_coarse, m["t_rand_seed"])
+    # the MLP seam with the reference's own encoded directions
+    s = orc.sample(t2n(inp["batch_xy"]), t2n(inp["batch_Rmats"]), t2n(inp["batch_Tvecs"]), t2n(inp["batch_inv_inmats"]),
+                   opt.num_sample_coarse, opt.world_z1, opt.world_z2, None if t_rand is None else t2n(t_rand))
+    ns = opt.num_sample_coarse
+    vd = np.repeat(g["vd_embed_ray"][:, :, :, None], ns, axis=3)
+    rgb, dens = orc.mlp(sd, orc.embed(s["pts"]), t2n(inp["shape_code"]), t2n(inp["appea_code"]), t2n(inp["audiostyle"]), vd=vd)
+    np.testing.assert_allclose(rgb, g["feat"], atol=2e-4)
+    np.testing.assert_allclose(dens.reshape(g["density"].shape), g["density"], atol=2e-4)
+    out = orc.forward(sd, opt, inp, t_rand, include_vd=True)
+    np.testing.assert_allclose(out["fg_feat"], g["fg_feat"], atol=2e-4)
+    np.testing.assert_allclose(out["bg_alpha"], g["bg_alpha"], atol=1e-4)
+    assert np.abs(out["merge_img"] - g["merge_img"]).max() <= 1e-3
+    # and the direction must matter: the same weights without it give a different image
+    assert np.abs(orc.forward({k: (v[:, list(range(384)) + list(range(411, 538))] if k.endswith("RGB_layer_1.weight") else v)
+                               for k, v in sd.items()}, opt, inp, t_rand)["fg_feat"] - g["fg_feat"]).max() > 1e-3

@@ -221,6 +221,58 @@ def gen_tiny(HeadNeRFNet, mode):
     }))
 
 
+def gen_vd(HeadNeRFNet, mode):
+    """include_vd=True (NetWorks/HeadNeRFNet.py:56-63,86,141-142; no caller of the reference sets it, the module supports it):
+    B=2, fs=8, N_s=8, pred 32.  The seams where the view direction enters (the encoded directions, the MLP's outputs), the
+    images, and -- train mode -- the gradients of every parameter / latent / camera input and one Adam step."""
+    opt = BaseOptions({"featmap_size": 8, "featmap_nc": 256, "pred_img_size": 32, "num_sample_coarse": 8})
+    B = 2
+    sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1, include_vd=True)
+    net = HeadNeRFNet(opt, include_vd=True, hier_sampling=False)
+    net.load_state_dict(sd, strict=True)  # the key inventory and the 538-wide RGB_layer_1 match the reference
+    inp = syn.frame_inputs(opt, B, yaw_range=0.3)
+    for k in ("audiostyle", "shape_code", "appea_code", "batch_Rmats", "batch_Tvecs"):
+        inp[k] = inp[k].clone().requires_grad_(True)
+    t_rand = syn.stratified_noise(B, opt.featmap_size ** 2, opt.num_sample_coarse) if mode == "train" else None
+    vd_seam = {}
+    h = net.vd_encoder.register_forward_hook(lambda _m, _i, out: vd_seam.__setitem__("vd", out))
+    coarse, s = run_seams(net, inp, mode, t_rand)
+    h.remove()
+    gt = torch.full_like(coarse["merge_img"], 0.5)
+    mask = disk_mask(B, opt.pred_img_size)
+    bg_l, head_l, nonhead_l = losses(coarse, gt, mask)
+    (bg_l + head_l + nonhead_l).backward()
+    arrays = {
+        "vd_embed_ray": np32(vd_seam["vd"][:, :, :, 0]),   # [B,27,N_r]: the encoding is the same at every sample of a ray
+        "feat": np32(s["mlp"][0]), "density": np32(s["mlp"][1]),
+        "fg_feat": np32(s["color"][0]), "bg_alpha": np32(s["color"][1]), "merge_featmap": np32(s["merge_featmap"]),
+        "merge_img": np32(coarse["merge_img"]), "bg_img": np32(coarse["bg_img"]),
+        "loss_terms": np.array([bg_l.item(), head_l.item(), nonhead_l.item()], dtype=np.float64),
+    }
+    assert float((vd_seam["vd"][:, :, :, 0:1] - vd_seam["vd"]).abs().max()) == 0.0
+    for k in ("audiostyle", "shape_code", "appea_code", "batch_Rmats", "batch_Tvecs"):
+        arrays["grad_in." + k] = np32(inp[k].grad)
+    for pname, p in net.named_parameters():
+        g = sample_grad(pname, p.grad)
+        for kk, vv in g.items():
+            arrays["grad_p.%s.%s" % (pname, kk)] = vv
+    # the 27 view-direction columns of RGB_layer_1 in full (192 x 27)
+    arrays["grad_vd_columns"] = np32(net.fg_CD_predictor.RGB_layer_1.weight.grad[:, 384:411, 0, 0])
+    optim = torch.optim.Adam(net.parameters(), lr=1e-4)
+    optim.step()
+    for pname, p in net.named_parameters():
+        flat = p.detach().reshape(-1)
+        idx = torch.from_numpy(arrays["grad_p.%s.idx" % pname])
+        arrays["adam_p.%s.val" % pname] = flat[idx].numpy()
+    name = "vd_" + mode
+    save(name, arrays, manifest_base(name, opt, {
+        "batch": B, "mode": mode, "weights_seed": 0, "bg_noise": 0.1, "yaw_range": 0.3, "include_vd": True,
+        "t_rand_seed": 7 if mode == "train" else None,
+        "weights_checksum": syn.state_dict_checksum(sd),
+        "loss": "bg+head+nonhead MSE, gt=0.5, disk mask r=0.35*size, bg_value=1",
+    }))
+
+
 def gen_cfg(HeadNeRFNet, name, fs, ns, pred, ray_step, B=1, crop=None, mode="test"):
     opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": pred, "num_sample_coarse": ns})
     sd = syn.make_state_dict(opt, seed=0, bg_noise=0.1)
@@ -576,6 +628,8 @@ def main():
         "render_utils": lambda: gen_render_utils(HeadNeRFNetNoAudio),
         "loss": gen_loss,
         "contrast": lambda: gen_contrast(HeadNeRFNet),
+        "vd_test": lambda: gen_vd(HeadNeRFNet, "test"),
+        "vd_train": lambda: gen_vd(HeadNeRFNet, "train"),
     }
     for k, fn in jobs.items():
         if args.only is None or k in args.only:
