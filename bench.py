@@ -13,19 +13,26 @@ Contract: python bench.py --gpus N --steps K --warmup W  -> rank 0 prints ONE JS
   torch, never touches the GPU) and starts N ranks of itself (n3dt/launch.py); under `torch.distributed.run`
   (WORLD_SIZE set) it is one of the ranks and WORLD_SIZE must equal --gpus.
 Extra objects in the line:
-  roofline      the fused MLP kernel: algorithmic FLOP (2 702 592 per sample point)
-                / its average launch time (hipEvents recorded around that launch on its stream,
-                inside the timed region) against the dense bf16 MFMA peak.
-  cpu_baseline  the CPU restatement (oracle/, an OpenMP port -- the reference's Python cannot
-                travel to the GPU box) timed on this host's cores on one frame of the workload.
+  roofline      the fused MLP kernel: algorithmic FLOP (2 702 592 per sample point) / its average launch time
+                (hipEvents recorded around that launch on its stream, inside the timed region) against the dense bf16 MFMA
+                peak; `traffic` = HBM bytes per launch from profiles/traffic.json with the hash of the build it was taken on
+                (`traffic_lib_sha16`) next to the hash of the library running (`lib_sha16`).
+  cpu_baseline  the CPU restatement (oracle/, an OpenMP port -- the reference's Python cannot travel to the GPU box) timed on
+                this host's cores on one frame of the workload.
   parity_check  (N = 1) the frame the CPU baseline rendered, rendered by the GPU in bf16 / bf16x3 / fp32 outside the timed
-                region: RGB L-inf against the oracle on the bench's weights and on the sharp-density `contrast` weights.
-                The run exits non-zero when fp32 or bf16x3 exceed 1e-3.
-  parity_grade  (N = 1) throughput of the MFMA mode that holds 1e-3 on every fixture (bf16x3), beside the bf16 headline.
+                region against the oracle, on the bench's weights, on the hand-scaled `contrast` weights and (`trained`, four
+                precisions, config 4's geometry) on a network the build's own fp32 trainer made sharp.  The run exits non-zero
+                when fp32 or bf16x3 exceed 1e-3.
+  parity_grade  (N = 1) throughput of the MFMA mode that holds 1e-3 on every weight set (bf16x3), beside the bf16 headline.
   sustained     (N = 1) >= 3 s of back-to-back headline steps: ms/step and the fused kernel's mean launch time there.
-  extra         (N = 1 only) the other BASELINE configurations and modes, a few timed steps each:
-                cfg2-N (512^2 rays), cfg2-R in exact fp32, cfg2-R one head (latency), cfg3 training
-                step in bf16 and fp32, cfg4 (R and N), cfg5 (R and N), single-image fitting in both training precisions.
+  extra         (N = 1 only) the other BASELINE configurations and modes, a few timed steps each: cfg2-N, cfg2-R in fp32 / fp16 /
+                bf16x3 / one head, the config-3 and config-4 (B = 4) training steps eager and as one hipGraph replay, cfg4, cfg5
+                (R and N), single-image fitting in both training precisions.
+  summary       (N = 1, LAST key; the same scalars are merged into `config`, which the driver's record keeps): parity per
+                precision and weight set, sustained ms / kernel ms / fraction, parity-grade frames/s, the training steps' ms,
+                host enqueue ms, fraction of the bf16 peak and volumetric kernels' ms.
+--mode train prints the training line: its `roofline` is 3 x 2 702 592 FLOP per point over the three volumetric stages' hipEvent
+spans (`frac`, `fwd_kernel_ms`, `dx_chain_ms`, `dw_stage_ms`) and over the step (`step_frac`), `traffic` their HBM bytes per step.
 """
 import argparse
 import ctypes
