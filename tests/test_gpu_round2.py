@@ -195,11 +195,12 @@ def test_fused_loss_tail_against_the_reference(case):
                           torch.from_numpy(g[k + "mask"]).to(dev()))
 
 
-@pytest.mark.parametrize("tiling", ["2", "3"])
+@pytest.mark.parametrize("tiling", ["3"])
 def test_run_time_kernel_variants_match_the_default(tiling, tmp_path):
-    """N3DT_X16_TILING = 2 (4 waves x 64 samples) and 3 (16x16x32 MFMA, nerf_fwd_x16b.hip) ship in the library as run-time
-    switches: both against the default tiling and against the reference fixtures (cfg1: 32 samples = one block per ray;
-    tiny_train: ragged 8-sample blocks, jitter).  The switch is read once per process, hence child processes."""
+    """N3DT_X16_TILING = 3 (16x16x32 MFMA, nerf_fwd_x16b.hip) ships in the library as a run-time switch: against the default
+    tiling and against the reference fixtures (cfg1: 32 samples = one block per ray; tiny_train: ragged 8-sample blocks,
+    jitter).  The switch is read once per process, hence child processes.  (Tiling 2, 4 waves x 64 samples, was withdrawn in
+    round 4: a diagnostic build exposed a latent ordering hazard in that instantiation -- nerf_fwd_x16.hip, tools/tiling_probe.py.)"""
     tool = os.path.join(REPO, "tools", "variant_check.py")
     for name in ("cfg1", "tiny_train"):
         outs = {}
