@@ -169,6 +169,12 @@ def test_stream_hazard_scanner_flags_scalar_and_flat_accesses(tmp_path):
         f.write_text("_Z1kv:\n" + body + "\ts_endpgm\n")
         found = mod.scan_inflight(str(f))
         assert (len(found) == 0) == (name == "waited"), (name, found)
+    # round 4: the transposed reads of the weight-gradient / blur kernels (several per asm block) are tracked too
+    tr = "\t;;#ASMSTART\n\tds_read_b64_tr_b16 v[0:1], v9 offset:0\n\tds_read_b64_tr_b16 v[2:3], v9 offset:256\n\t;;#ASMEND\n"
+    for name, body, n in (("tr_waited", tr + wait + use, 0), ("tr_touched", tr + "\tv_mov_b32_e32 v12, v3\n" + wait + use, 1)):
+        f = tmp_path / (name + ".s")
+        f.write_text("_Z1kv:\n" + body + "\ts_endpgm\n")
+        assert len(mod.scan_inflight(str(f))) == n, name
 
 
 def _shipped_asm():

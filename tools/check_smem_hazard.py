@@ -53,6 +53,18 @@ def _vregs(tok):
     return {int(m.group(1))} if m else set()
 
 
+def _in_asm_block(lines, i):
+    """line i sits between ;;#ASMSTART and ;;#ASMEND"""
+    j = i - 1
+    while j >= 0 and i - j < 64:
+        if "ASMEND" in lines[j]:
+            return False
+        if "ASMSTART" in lines[j]:
+            return True
+        j -= 1
+    return False
+
+
 def scan_inflight(path):
     """Second check: between an inline-asm fragment read (ds_read_b128) and the counted wait that retires it, nothing may
     read or write its destination registers.  hipcc does not know the read is asynchronous: a copy, a spill, or -- when the
@@ -75,7 +87,9 @@ def scan_inflight(path):
             continue
         if not t or t.startswith(";") or t.startswith("."):
             continue
-        if t.startswith("ds_read_b128") and "ASMSTART" in lines[i - 1]:
+        # every LDS read issued from inline asm: the stream's ds_read_b128 fragments and (round 4) the transposed
+        # ds_read_b64_tr_b16 reads of the weight-gradient and matrix-pipe blur kernels (x16_tr_issue; several per asm block)
+        if t.startswith("ds_read") and _in_asm_block(lines, i):
             pending.append((_vregs(t.split()[1].rstrip(",")), i))
             continue
         if t.startswith("s_waitcnt"):
