@@ -199,7 +199,19 @@ def forward(sd, opt, inp, t_rand=None, skip_neural_render=False, include_vd=Fals
     return {"fg_feat": fg, "bg_alpha": ba, "merge_img": merge_img, "bg_img": bg_img}
 
 
-def forward_hier(sd, opt, inp, t_rand=None, fine_u=None):
+def embed_dirs(ray_d, n_samples, n_freqs=4):
+    """vd_encoder(fg_dirs) (HeadNeRFNet.py:141-142): ray_d [B,3,Nr] -> [B, 3 + 6 n_freqs, Nr, n_samples] (numpy fp32, the encoder's
+    channel order of NetWorks/utils.py:20-51; the direction is the same at every sample of a ray)."""
+    d = _f32(ray_d)
+    feats = [d]
+    for k in range(n_freqs):
+        a = (d * np.float32(2.0 ** k)).astype(np.float32)
+        feats += [np.sin(a, dtype=np.float32), np.cos(a, dtype=np.float32)]
+    pe = np.concatenate(feats, axis=1)
+    return np.ascontiguousarray(np.repeat(pe[:, :, :, None], n_samples, axis=3))
+
+
+def forward_hier(sd, opt, inp, t_rand=None, fine_u=None, include_vd=False):
     """Coarse pass + hierarchical pass (HeadNeRFNet._forward with hier_sampling=True, the call at HeadNeRFNet.py:182-185
     completed with its two missing arguments).  Returns the fine planes and both passes' composited features / images."""
     import math
@@ -211,11 +223,13 @@ def forward_hier(sd, opt, inp, t_rand=None, fine_u=None):
     audio = _np(inp["audiostyle"]) if inp.get("audiostyle") is not None else None
     R, T, K = _np(inp["batch_Rmats"]), _np(inp["batch_Tvecs"]), _np(inp["batch_inv_inmats"])
     s = sample(xy, R, T, K, opt.num_sample_coarse, opt.world_z1, opt.world_z2, None if t_rand is None else _np(t_rand))
-    rgb, dens = mlp(sd, embed(s["pts"]), shape, appea, audio, C, opt.mlp_hidden_nchannels)
+    vd_c = embed_dirs(s["ray_d"], s["pts"].shape[-1]) if include_vd else None
+    rgb, dens = mlp(sd, embed(s["pts"]), shape, appea, audio, C, opt.mlp_hidden_nchannels, vd=vd_c)
     cfg, cba, _, cw = composite(rgb, dens, s["z_dists"], s["zvals"])
     planes = fine_sample(cw, s["zvals"], opt.num_sample_fine, None if fine_u is None else _np(fine_u))
     f = sample_planes(xy, R, T, K, planes)
-    rgb, dens = mlp(sd, embed(f["pts"]), shape, appea, audio, C, opt.mlp_hidden_nchannels, prefix="fine_fg_CD_predictor.")
+    vd_f = embed_dirs(s["ray_d"], f["pts"].shape[-1]) if include_vd else None
+    rgb, dens = mlp(sd, embed(f["pts"]), shape, appea, audio, C, opt.mlp_hidden_nchannels, prefix="fine_fg_CD_predictor.", vd=vd_f)
     ffg, fba, _, fw = composite(rgb, dens, f["z_dists"], f["zvals"])
     bg = _f32(_np(sd["neural_render.bg_featmap"]))
     out = {"planes": planes, "coarse_weight": cw, "coarse_fg": cfg, "fine_fg": ffg, "fine_bg_alpha": fba, "fine_weight": fw}

@@ -293,3 +293,35 @@ def test_include_vd_bf16_training_path_against_the_fp32_path():
         assert float((a * b).sum() / (a.norm() * b.norm() + 1e-30)) >= 0.995, k
     vd32 = g32["fg_CD_predictor.RGB_layer_1.weight"][:, 384:411]
     assert float(vd32.abs().max()) > 0
+
+
+def test_include_vd_with_the_hierarchical_pass_and_gaze():
+    """include_vd together with the other constructor arguments: hier_sampling=True (the fine network has its own 27 view-direction
+    columns; its per-ray bias is formed from the same directions) and include_gaze=True -- inference against the oracle's coarse +
+    fine passes, and the differentiable path: gradients reach both networks' view-direction columns."""
+    from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
+    from n3dt.train import data_losses, disk_mask
+    from oracle import oracle as orc
+    opt = BaseOptions({"featmap_size": 8, "featmap_nc": 256, "pred_img_size": 32, "num_sample_coarse": 16, "num_sample_fine": 24})
+    kw = {"include_gaze": True, "eye_gaze_dim": 64}
+    sd = syn.make_state_dict(opt, seed=2, bg_noise=0.1, hier_sampling=True, include_vd=True, **kw)
+    inp = syn.frame_inputs(opt, 2, **kw)
+    ref = orc.forward_hier(sd, opt, inp, include_vd=True)
+    d = to_dev(inp)
+    net = HeadNeRFNet(opt, include_vd=True, hier_sampling=True, **kw).to(dev())
+    net.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        out = net("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+                  d["batch_Tvecs"], d["batch_inv_inmats"])
+    assert np.abs(out["coarse_dict"]["merge_img"].cpu().numpy() - ref["coarse_merge_img"]).max() <= 1e-4
+    assert np.abs(out["fine_dict"]["merge_img"].cpu().numpy() - ref["fine_merge_img"]).max() <= 1e-3
+    # differentiable path: same images, and both networks' view-direction columns receive gradients
+    o2 = net("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+             d["batch_Tvecs"], d["batch_inv_inmats"])
+    assert float((o2["fine_dict"]["merge_img"].detach() - out["fine_dict"]["merge_img"]).abs().max()) <= 2e-5
+    t = data_losses(o2["fine_dict"], torch.full_like(o2["fine_dict"]["merge_img"], 0.5), disk_mask(2, 32).to(dev()))
+    t2 = data_losses(o2["coarse_dict"], torch.full_like(o2["coarse_dict"]["merge_img"], 0.5), disk_mask(2, 32).to(dev()))
+    (t["head_loss"] + t["nonhead_loss"] + t2["head_loss"] + t2["nonhead_loss"]).backward()
+    for name in ("fg_CD_predictor", "fine_fg_CD_predictor"):
+        g = getattr(net, name).RGB_layer_1.weight.grad
+        assert g is not None and float(g[:, 384:411].abs().max()) > 0 and float(g[:, :384].abs().max()) > 0 and float(g[:, 411:].abs().max()) > 0, name
