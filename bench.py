@@ -476,7 +476,9 @@ def parity_check(ctx, opt, sd, ref_seed0):
 
 def trained_parity(ctx):
     """a TRAINED network across the inference precisions.  Seed-0 weights at config 4's geometry, trained by the
-    build's own exact-fp32 path against a sharp target until alpha saturates on >= 20 % of the rays (a few seconds), then frame 0
+    build's own exact-fp32 path against a sharp target until every ray is opaque and >= 30 % of the rays are carried by ONE sample
+    (~200 Adam steps, a few seconds; profiles/r04_i_trained_parity_by_steps_*.log: the 16-bit modes' errors keep growing as
+    training goes on -- fp16 4e-4 at 100 steps, 1.6e-3 at 200, 4e-3 at 800 -- so this row is a lightly trained head), then frame 0
     rendered in bf16 / fp16 / bf16x3 / fp32 against the CPU oracle on those weights."""
     import numpy as np
     import torch
@@ -484,7 +486,7 @@ def trained_parity(ctx):
     from oracle import oracle as orc
     fs, ns, pred = GEOMETRY["cfg4"]
     opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": pred, "num_sample_coarse": ns})
-    net, info = syn.train_sharp_head(opt, ctx.dev, steps=400, lr=1e-3, batch=2)
+    net, info = syn.train_sharp_head(opt, ctx.dev, steps=600, lr=1e-3, batch=2, want_share=0.3)
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     del net
     one = syn.frame_inputs(opt, 1)

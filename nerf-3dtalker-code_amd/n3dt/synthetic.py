@@ -272,8 +272,8 @@ def train_sharp_head(opt, dev, steps=400, lr=1e-3, batch=2, train_precision="fp3
     differentiable path (`train_precision`, exact fp32 by default) on `batch` synthetic frames against sharp_target() with the
     reference's three data terms, stopping once alpha has saturated on `want_share` of the rays in both senses: the ray is opaque
     (bg_alpha < 0.01) AND one sample carries it (compositing weight > 0.9: a hard surface, what stresses 16-bit arithmetic).
-    Measured at config 4's geometry, lr 1e-3, B = 2: 150 - 200 steps (3 - 4 s), the loss falls 180-fold, 25 % of the rays end on
-    one sample, every ray is opaque.  Returns (net, info); info carries the alpha statistics."""
+    Measured at config 4's geometry, lr 1e-3, B = 2: 20 % one-sample rays after ~100 steps, 30 % after ~200 (3 - 4 s; the loss has
+    fallen 180-fold), 46 % after 800; every ray is opaque from step 25 on.  Returns (net, info); info carries the alpha statistics."""
     from . import HeadNeRFNet
     from .train import fused_data_losses
     net = HeadNeRFNet(opt, include_vd=False, hier_sampling=False, precision="fp32", train_precision=train_precision).to(dev)

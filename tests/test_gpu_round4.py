@@ -102,14 +102,14 @@ def test_whole_training_step_replays_as_one_graph():
 def test_a_network_trained_by_the_builds_own_trainer_across_the_inference_precisions():
     """VERDICT r3 #5.  The released checkpoints are absent (/root/reference/.MISSING_LARGE_BLOBS), so "does a 16-bit mode hold
     1e-3 on a trained head" is answered on a head the build's OWN exact-fp32 trainer makes sharp: seed-0 weights, config 4's
-    geometry, a disk of colour on white, Adam until alpha saturates on >= 20 % of the rays (opaque AND carried by one sample).
+    geometry, a disk of colour on white, Adam until alpha saturates on >= 30 % of the rays (opaque AND carried by one sample).
     Frame 0 is then rendered in four precisions against the CPU oracle ON THOSE WEIGHTS: fp32 and bf16x3 must hold the
     north-star's 1e-3; bf16 / fp16 report their own error (asserted only against garbage)."""
     from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
     from oracle import oracle as orc
     opt = BaseOptions({"featmap_size": 32, "featmap_nc": 256, "pred_img_size": 256, "num_sample_coarse": 64})
-    net, info = syn.train_sharp_head(opt, dev(), steps=400, lr=1e-3, batch=2)
-    assert info["alpha_saturated_ray_share"] >= 0.2 and info["one_sample_rays_share"] >= 0.2, info
+    net, info = syn.train_sharp_head(opt, dev(), steps=600, lr=1e-3, batch=2, want_share=0.3)
+    assert info["alpha_saturated_ray_share"] >= 0.3 and info["one_sample_rays_share"] >= 0.3, info
     assert info["loss_last"] < 0.05 * info["loss_first"], info
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     one = syn.frame_inputs(opt, 1)
