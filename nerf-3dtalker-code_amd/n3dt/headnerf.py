@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops, synthetic
+from .parallel import _graph_task_id as parallel_graph_task_id
 
 
 class _Conv1x1(nn.Module):
@@ -929,7 +930,7 @@ class HeadNeRFNet(nn.Module):
         fs, C = self.featmap_size, self.featmap_nc
         xy = batch_xy if batch_xy.dtype == torch.float32 else batch_xy.float()
         geom = self._geom(B, n_r, xy)
-        if self._grad_arena is not None and torch._C._current_graph_task_id() == -1:
+        if self._grad_arena is not None and parallel_graph_task_id() == -1:
             self._grad_arena.end_pass()  # (a backward that raised never told the arena that its pass was over)
         layers = self.fg_CD_predictor.layers()
         mlp = [m.weight for m in layers] + [m.bias for m in layers]

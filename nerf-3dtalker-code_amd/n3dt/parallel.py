@@ -15,6 +15,13 @@ import torch
 import torch.distributed as dist
 
 
+def _graph_task_id():
+    """Id of the autograd graph task now running (-1 outside backward).  A private torch hook (also used by torch.utils.checkpoint);
+    without it a new pass is recognised by the engine callback alone, as before round 4."""
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f() if f is not None else -1
+
+
 def shard_range(total, rank, world):
     """Contiguous frame range [lo, hi) of `rank`; the first total % world ranks take one extra frame."""
     base, extra = divmod(total, world)
@@ -80,7 +87,7 @@ class FlatGrads:
         idx = [self.index.get(id(p)) for p in params]
         if any(i is None for i in idx) or self.in_flight:
             return None
-        task = torch._C._current_graph_task_id()
+        task = _graph_task_id()
         if self._in_pass and task != self._pass_id:
             self.end_pass()  # the pass that set the flag never finished (its backward raised): this is a new one
         if not self._in_pass:
