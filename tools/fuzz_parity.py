@@ -1,5 +1,5 @@
 """Randomised parity sweep: HIP path (through the C ABI) against the CPU oracle on random geometries, batch sizes, variants and
-precisions.  usage: fuzz_parity.py [n_cases] [seed]   (exit code 1 on the first tolerance violation)"""
+precisions.  usage: [N3DT_FUZZ_VD=0.5] fuzz_parity.py [n_cases] [seed]   (exit code 1 on the first tolerance violation)"""
 import os
 import sys
 
@@ -21,6 +21,9 @@ FEAT_TOL = {"fp32": 5e-5, "bf16x3": 5e-5, "fp16": 2e-3, "bf16": 8e-3}
 ALPHA_TOL = {"fp32": 5e-5, "bf16x3": 1e-4, "fp16": 5e-3, "bf16": 3e-2}
 
 
+VD_SHARE = float(os.environ.get("N3DT_FUZZ_VD", "0"))  # share of the cases drawn with include_vd=True
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -33,6 +36,8 @@ def main():
         B = int(rng.choice([1, 2, 3, 5]))
         variant = rng.choice(["plain", "plain", "gaze", "noaudio"])
         train = bool(rng.rand() < 0.4)
+        vd = bool(VD_SHARE > 0 and rng.rand() < VD_SHARE)  # include_vd=True (round 4); drawn only when asked for, so that the seeds of
+        #                                                     earlier rounds keep drawing the same cases
         opt = BaseOptions({"featmap_size": fs, "featmap_nc": 256, "pred_img_size": fs << nblk, "num_sample_coarse": ns})
         kw = {}
         if variant == "gaze":
@@ -40,15 +45,15 @@ def main():
         elif variant == "noaudio":
             kw = {"audio_dim": 0}
         seed = int(rng.randint(0, 1000))
-        sd = syn.make_state_dict(opt, seed=seed, bg_noise=0.2, **kw)
+        sd = syn.make_state_dict(opt, seed=seed, bg_noise=0.2, include_vd=vd, **kw)
         inp = syn.frame_inputs(opt, B, yaw_range=0.5, first_frame=int(rng.randint(0, 100)), **kw)
         if variant == "noaudio":
             inp["audiostyle"] = None
         t_rand = syn.stratified_noise(B, fs * fs, ns, seed=seed + 1) if train else None
-        ref = orc.forward(sd, opt, inp, t_rand)
+        ref = orc.forward(sd, opt, inp, t_rand, include_vd=vd)
         d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
         for prec in RGB_TOL:
-            net = HeadNeRFNet(opt, False, False, precision=prec, **kw).to(dev)
+            net = HeadNeRFNet(opt, vd, False, precision=prec, **kw).to(dev)
             net.load_state_dict(sd, strict=True)
             with torch.no_grad():
                 f = net.render_features(d["batch_xy"], d["audiostyle"], d["shape_code"], d["appea_code"], d["batch_Rmats"], d["batch_Tvecs"],
@@ -69,7 +74,8 @@ def main():
                 print("FAIL case %d: fs %d -> %d, ns %d, B %d, %s, %s, seed %d, %s: feat %.2e alpha %.2e rgb %.2e bg %.2e" % (
                     case, fs, fs << nblk, ns, B, variant, "train" if train else "test", seed, prec, e_f, e_a, e_i, e_b))
                 return 1
-        print("case %2d ok: fs %2d -> %3d, ns %3d, B %d, %-7s %s" % (case, fs, fs << nblk, ns, B, variant, "train" if train else "test"), flush=True)
+        print("case %2d ok: fs %2d -> %3d, ns %3d, B %d, %-7s %s%s" % (case, fs, fs << nblk, ns, B, variant, "train" if train else "test",
+                                                                       " include_vd" if vd else ""), flush=True)
     print("all %d cases passed; worst RGB error per precision: %s" % (n_cases, {k: "%.1e" % v for k, v in worst.items()}))
     return 0
 
