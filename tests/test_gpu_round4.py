@@ -325,3 +325,35 @@ def test_include_vd_with_the_hierarchical_pass_and_gaze():
     for name in ("fg_CD_predictor", "fine_fg_CD_predictor"):
         g = getattr(net, name).RGB_layer_1.weight.grad
         assert g is not None and float(g[:, 384:411].abs().max()) > 0 and float(g[:, :384].abs().max()) > 0 and float(g[:, 411:].abs().max()) > 0, name
+
+
+@pytest.mark.parametrize("tp", ["fp32", "bf16"])
+def test_include_vd_frozen_network_gives_the_same_input_gradients(tp):
+    """Single-image fitting (FittingSingleImage_new.py:826-859) freezes the network and optimises codes and cameras.  With
+    include_vd the rotation's gradient has a route through the ray direction: the frozen backward (no weight-gradient stage) must
+    return the same d codes / d cameras as the full one."""
+    from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
+    from n3dt.train import data_losses, disk_mask
+    opt = BaseOptions({"featmap_size": 16, "featmap_nc": 256, "pred_img_size": 64, "num_sample_coarse": 32})
+    sd = syn.make_state_dict(opt, seed=1, bg_noise=0.1, include_vd=True)
+    names = ("audiostyle", "shape_code", "appea_code", "batch_Rmats", "batch_Tvecs")
+
+    def grads(frozen):
+        net = HeadNeRFNet(opt, include_vd=True, hier_sampling=False, train_precision=tp).to(dev())
+        net.load_state_dict(sd, strict=True)
+        if frozen:
+            for p in net.parameters():
+                p.requires_grad_(False)
+        d = to_dev(syn.frame_inputs(opt, 1))
+        for k in names:
+            d[k] = d[k].clone().requires_grad_(True)
+        out = net("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+                  d["batch_Tvecs"], d["batch_inv_inmats"])["coarse_dict"]
+        t = data_losses(out, torch.full_like(out["merge_img"], 0.5), disk_mask(1, 64).to(dev()))
+        (t["bg_loss"] + t["head_loss"] + t["nonhead_loss"]).backward()
+        return {k: d[k].grad.detach().clone() for k in names if d[k].grad is not None}
+    full, froz = grads(False), grads(True)
+    assert set(full) == set(froz) == set(names)
+    for k in names:
+        scale = float(full[k].abs().max())
+        assert float((full[k] - froz[k]).abs().max()) <= (2e-4 if tp == "fp32" else 2e-3) * scale + 1e-12, k
