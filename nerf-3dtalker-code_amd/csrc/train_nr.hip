@@ -439,20 +439,19 @@ __global__ void nrt_rgb_bias_kernel(int nb, int HW, const float* __restrict__ d_
 
 // feat_2_rgb weight gradient: dW[k][c] += sum over images and pixels of d_rgb[img][k][pix] * net[img][pix][c]
 // (a 3 x co result over up to 10^6 pixels: a reduction, not a GEMM).  Thread = 4 adjacent channels x one pixel lane;
-// block = NRT_WG_PIX consecutive pixels of one image; co in {32, 64, 128, 256}.
-#define NRT_WG_PIX 512
+// block = wg_pix consecutive pixels of one image (launch_to_rgb_wgrad picks it); co in {32, 64, 128, 256}.
 // db (nullable): the bias gradient db[k] += sum over pixels of d_rgb[img][k][pix] rides on the channel-group-0 threads, which
 // load d_rgb anyway (the stand-alone nrt_rgb_bias_kernel re-read it: one launch per level).
 template <class T>
-__global__ __launch_bounds__(256) void nrt_to_rgb_wgrad_kernel(int HW, int co, const float* __restrict__ d_rgb,
+__global__ __launch_bounds__(256) void nrt_to_rgb_wgrad_kernel(int HW, int co, int wg_pix, const float* __restrict__ d_rgb,
                                                                const T* __restrict__ net, float* __restrict__ dW, float* __restrict__ db) {
     __shared__ float red[256][13];
     float bsum[3] = {0.0f, 0.0f, 0.0f};
     const int cg = co >> 2, lanes = 256 / cg;
     const int t = threadIdx.x, c4 = (t % cg) * 4, pl = t / cg;
-    const int chunks = (HW + NRT_WG_PIX - 1) / NRT_WG_PIX;
-    const int img = blockIdx.x / chunks, p0 = (blockIdx.x % chunks) * NRT_WG_PIX;
-    const int p1 = min(HW, p0 + NRT_WG_PIX);
+    const int chunks = (HW + wg_pix - 1) / wg_pix;
+    const int img = blockIdx.x / chunks, p0 = (blockIdx.x % chunks) * wg_pix;
+    const int p1 = min(HW, p0 + wg_pix);
     const float* d = d_rgb + (size_t)img * 3 * HW;
     const T* x = net + (size_t)img * HW * co + c4;
     float acc[3][4];
@@ -515,8 +514,16 @@ __global__ __launch_bounds__(256) void nrt_to_rgb_wgrad_kernel(int HW, int co, c
 }
 template <class T>
 static void launch_to_rgb_wgrad(int nb, int HW, int co, const float* d_rgb, const T* net, float* dW, hipStream_t s, float* db = nullptr) {
-    const int chunks = (HW + NRT_WG_PIX - 1) / NRT_WG_PIX;
-    hipLaunchKernelGGL(nrt_to_rgb_wgrad_kernel<T>, dim3(nb * chunks), dim3(256), 0, s, HW, co, d_rgb, net, dW, db);
+    // pixels per workgroup: as many as leave ~512 workgroups (every workgroup ends in 3 co
+    // same-address atomics: 1 536 workgroups x 96 atomics on 96 addresses were a third of the 44 us this took at 3 x 512^2)
+    static const int target = [] {
+        const char* e = getenv("N3DT_NR_RGBW_WGS");
+        return e ? atoi(e) : 512;
+    }();
+    long pix = ((long)nb * HW + target - 1) / target;
+    pix = (pix + 63) / 64 * 64;  // small maps (2 x 32^2 at 256 channels): 64-pixel workgroups instead of four of 512
+    const int chunks = (int)((HW + pix - 1) / pix);
+    hipLaunchKernelGGL(nrt_to_rgb_wgrad_kernel<T>, dim3(nb * chunks), dim3(256), 0, s, HW, co, (int)pix, d_rgb, net, dW, db);
 }
 
 #define GRID1(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256)
