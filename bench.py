@@ -85,7 +85,10 @@ class Ctx:
             raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with `python bench.py --gpus N` or "
                              "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)" % (args.gpus, self.world))
         self.cpus_bound = None
-        if self.world > 1:
+        # N3DT_DIST_FORCE=1: take the N > 1 code path (process group, collectives, gradient reducer) with ONE rank -- the only
+        # way to run that path over RCCL on a one-GPU box (profiles/r04_o_*)
+        self.collective = self.world > 1 or os.environ.get("N3DT_DIST_FORCE") == "1"
+        if self.collective:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -101,7 +104,7 @@ class Ctx:
         dev_index = local_rank if self.backend == "nccl" else local_rank % max(ndev, 1)
         torch.cuda.set_device(dev_index)
         self.dev = torch.device("cuda", dev_index)
-        if self.world > 1:
+        if self.collective:
             if self.backend == "nccl":
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
             else:
@@ -112,13 +115,13 @@ class Ctx:
         import torch
         import torch.distributed as dist
         torch.cuda.synchronize()
-        if self.world > 1:
+        if self.collective:
             dist.barrier()
 
     def max_over_ranks(self, seconds):
         import torch
         import torch.distributed as dist
-        if self.world == 1:
+        if not self.collective:
             return seconds
         t = torch.tensor([seconds], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -128,7 +131,7 @@ class Ctx:
         """Number of ranks the collective backend actually connects (an all-reduce of ones)."""
         import torch
         import torch.distributed as dist
-        if self.world == 1:
+        if not self.collective:
             return 1
         t = torch.ones(1, dtype=torch.float32, device=self.dev if self.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -136,7 +139,7 @@ class Ctx:
 
     def close(self):
         import torch.distributed as dist
-        if self.world > 1:
+        if self.collective:
             dist.destroy_process_group()
 
 
@@ -257,12 +260,13 @@ def run_train(ctx, config, train_precision, batch, steps, warmup, audio2style_bu
     gt = torch.full((batch, 3, pred, pred), 0.5, device=ctx.dev)
     mask = disk_mask(batch, pred).to(ctx.dev)
     reducer = None
-    if ctx.world > 1:
+    if ctx.collective:
         assert not graph, "the graphed step is a one-GPU form (a collective inside a captured backward is not rehearsable here)"
-        parallel.broadcast_parameters(net)
+        parallel.broadcast_parameters(net, force=ctx.world == 1)
         # two buckets, reduced in place (no cat, no copy-back): HeadNeRFNet's gradient arena goes out from inside backward as soon
         # as its last gradient is in, the co-trained module's bucket after it; both are joined before the optimizer steps
-        reducer = parallel.GradReducer([net.grad_arena()] + ([bucket.parameters()] if bucket is not None else []), ctx.world)
+        reducer = parallel.GradReducer([net.grad_arena()] + ([bucket.parameters()] if bucket is not None else []), ctx.world,
+                                       force=ctx.world == 1)
 
     def step():
         pred_ = net("train", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"],

@@ -321,12 +321,12 @@ class GradReducer:
         self._hooks = []
 
 
-def broadcast_parameters(module, src=0, group=None):
+def broadcast_parameters(module, src=0, group=None, force=False):
     """Make every rank start from rank `src`'s weights (and buffers): ONE broadcast of a flat buffer, copied back
     into the tensors under no_grad.  The copy moves the version counters (a collective writing a tensor in place does
     not), so packed copies of the weights are rebuilt; modules that keep such copies (HeadNeRFNet.invalidate_packed)
-    are told explicitly as well."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    are told explicitly as well.  force=True broadcasts in a one-rank group too (rehearsals of the N > 1 path)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return
     tensors = list(module.parameters()) + list(module.buffers())
     by_kind = {}
