@@ -357,3 +357,21 @@ def test_include_vd_frozen_network_gives_the_same_input_gradients(tp):
     for k in names:
         scale = float(full[k].abs().max())
         assert float((full[k] - froz[k]).abs().max()) <= (2e-4 if tp == "fp32" else 2e-3) * scale + 1e-12, k
+
+
+def test_maximum_size_batches_equal_their_frames_rendered_alone():
+    """Size-independent property at sizes past every 32-bit limit (tools/big_batch_probe.py): frames are independent, so a batch
+    rendered in one call equals the same frames rendered one at a time, bit for bit -- 20 reading-N frames of config 2 in one call
+    (5.2 M rays, 336 M sample points, fg_feat 1.25 G floats = 5.4 GB: element offsets past 2^30, byte offsets past 2^32), 64 heads
+    through the whole forward, and 16 heads in one fused-bf16 training step (latent-code gradients of a head, times the batch size,
+    equal the one-head step's up to the order of fp32 atomic sums)."""
+    import importlib.util
+    from n3dt import BaseOptions
+    spec = importlib.util.spec_from_file_location("big_batch_probe", os.path.join(os.path.dirname(__file__), "..", "tools", "big_batch_probe.py"))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    opt = BaseOptions({"featmap_size": 64, "featmap_nc": 256, "pred_img_size": 512, "num_sample_coarse": 64})
+    assert probe.render_sections(dev(), opt, 20, "bf16") == 0
+    torch.cuda.empty_cache()
+    assert probe.train_section(dev(), opt, 16) == 0
+    torch.cuda.empty_cache()
