@@ -1,5 +1,6 @@
 """Round-4 GPU tests: RCCL on the device path (one-rank group), config 4's training shape (B = 4), the whole training step as
 one hipGraph replay, a network trained by the build's own trainer across the inference precisions, include_vd."""
+import contextlib
 import json
 import os
 import subprocess
@@ -375,3 +376,45 @@ def test_maximum_size_batches_equal_their_frames_rendered_alone():
     torch.cuda.empty_cache()
     assert probe.train_section(dev(), opt, 16) == 0
     torch.cuda.empty_cache()
+
+
+def test_all_work_is_enqueued_on_the_callers_stream():
+    """Boundary contract (include/n3dt.h: every entry point takes the stream; SURVEY 8b "all work on the current stream"): with the
+    default stream kept busy for ~0.5 s, an inference forward, a hierarchical forward and three training steps issued on a side
+    stream -- and joined by synchronising THAT stream only -- equal the default-stream run.  Anything the library or the host code
+    put on the null stream (a memset, a copy, a pack) would still be queued behind the busy work when the side stream finishes."""
+    from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
+
+    def run(side):
+        torch.manual_seed(0)
+        net, step, _ = _train_setup(16, 32, 64, 2, graph=False)
+        opt = BaseOptions({"featmap_size": 16, "featmap_nc": 256, "pred_img_size": 64, "num_sample_coarse": 32, "num_sample_fine": 16})
+        hier = HeadNeRFNet(opt, False, True).to(dev())
+        hier.load_state_dict(syn.make_state_dict(opt, seed=2, bg_noise=0.1, hier_sampling=True), strict=True)
+        d = to_dev(syn.frame_inputs(opt, 2))
+        call = lambda n: n("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"],  # noqa: E731
+                           d["batch_Rmats"], d["batch_Tvecs"], d["batch_inv_inmats"])
+        torch.cuda.synchronize()
+        busy = None
+        if side is not None:
+            x = torch.randn(8192, 8192, device=dev())
+            for _ in range(40):          # ~0.5 s of fp32 GEMMs on the default stream, not waited for below
+                busy = x @ x
+        ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+        with ctx:
+            with torch.no_grad():
+                img = call(net)["coarse_dict"]["merge_img"].clone()
+                o = call(hier)
+                fine = o["fine_dict"]["merge_img"].clone()
+            losses = [step() for _ in range(3)]
+            w = net.fg_CD_predictor.FeaExt_module_3.weight.detach().clone()
+        (side.synchronize() if side is not None else torch.cuda.synchronize())
+        res = (img.cpu(), fine.cpu(), torch.stack(losses).cpu(), w.cpu())
+        torch.cuda.synchronize()
+        del busy
+        return res
+    ref = run(None)
+    got = run(torch.cuda.Stream())
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+    assert float((ref[2] - got[2]).abs().max()) <= 2e-4 * float(ref[2].abs().max())     # fp32 atomics of the bf16 training path
+    assert float((ref[3] - got[3]).abs().max()) <= 1e-4
