@@ -418,3 +418,55 @@ def test_all_work_is_enqueued_on_the_callers_stream():
     assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
     assert float((ref[2] - got[2]).abs().max()) <= 2e-4 * float(ref[2].abs().max())     # fp32 atomics of the bf16 training path
     assert float((ref[3] - got[3]).abs().max()) <= 1e-4
+
+
+def test_two_threads_two_streams_two_networks():
+    """The C ABI is re-entrant (include/n3dt.h: no state but the thread-local error string): two host threads, each with its own
+    network (different geometry and precision), its own stream and 30 forwards + 2 training steps, running at the same time
+    (ctypes releases the GIL inside every entry point), give what each gives alone."""
+    import threading
+    from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
+    from n3dt.train import fused_data_losses, disk_mask
+    specs = [dict(fs=16, ns=32, pred=64, prec="bf16", seed=0, vd=False), dict(fs=8, ns=24, pred=32, prec="fp16", seed=5, vd=True)]
+
+    def work(sp, stream, out):
+        try:
+            opt = BaseOptions({"featmap_size": sp["fs"], "featmap_nc": 256, "pred_img_size": sp["pred"], "num_sample_coarse": sp["ns"]})
+            with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                net = HeadNeRFNet(opt, sp["vd"], False, precision=sp["prec"], train_precision="bf16").to(dev())
+                net.load_state_dict(syn.make_state_dict(opt, seed=sp["seed"], bg_noise=0.1, include_vd=sp["vd"]), strict=True)
+                d = to_dev(syn.frame_inputs(opt, 2))
+                a = (d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"],
+                     d["batch_Tvecs"], d["batch_inv_inmats"])
+                with torch.no_grad():
+                    for _ in range(30):
+                        img = net("test", *a)["coarse_dict"]["merge_img"]
+                    img = img.clone()
+                t_rand = syn.stratified_noise(2, sp["fs"] ** 2, sp["ns"], seed=3).to(dev())
+                gt, mask = torch.full((2, 3, sp["pred"], sp["pred"]), 0.5, device=dev()), disk_mask(2, sp["pred"]).to(dev())
+                for _ in range(2):
+                    net.zero_grad()
+                    loss = fused_data_losses(net("train", *a, t_rand=t_rand)["coarse_dict"], gt, mask)["total_loss"]
+                    loss.backward()
+                g = net.fg_CD_predictor.FeaExt_module_2.weight.grad.detach().clone()
+                (stream.synchronize() if stream is not None else torch.cuda.synchronize())
+                out.update(img=img.cpu(), loss=float(loss.detach()), g=g.cpu())
+        except BaseException as e:  # noqa: BLE001  (reported by the main thread)
+            out["error"] = repr(e)
+
+    alone = [dict(), dict()]
+    for sp, o in zip(specs, alone):
+        work(sp, None, o)
+        assert "error" not in o, o
+    both = [dict(), dict()]
+    threads = [threading.Thread(target=work, args=(sp, torch.cuda.Stream(), o)) for sp, o in zip(specs, both)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for a, b in zip(alone, both):
+        assert "error" not in b, b
+        assert torch.equal(a["img"], b["img"])
+        assert abs(a["loss"] - b["loss"]) <= 1e-4 * abs(a["loss"])
+        assert float((a["g"] - b["g"]).abs().max()) <= 2e-2 * float(a["g"].abs().max())   # fp32 atomics of the bf16 path
