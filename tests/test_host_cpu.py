@@ -286,3 +286,48 @@ def test_every_stream_rendezvous_waits_for_its_lds_dma():
                     j -= 1
                 assert found, "%s: s_barrier at line %d of %s has no vmcnt wait in front of it" % (kernel, i + 1, os.path.basename(path))
     assert n_dma_kernels >= 30 and n_barriers >= 1000
+
+
+def test_entry_points_refuse_bad_arguments_before_any_launch():
+    """include/n3dt.h: "return 0 on success, a negative N3DT_E* code otherwise; never throws, never exits".  NULL arguments, an
+    undersized workspace / saved buffer, a per-ray bias without vd_dim (and vd_dim without it), an unknown precision: every entry
+    point of the path answers with its error code and a message naming itself -- checked here without a device (the checks run
+    before the first HIP call; the pointers below are never dereferenced)."""
+    from n3dt import _lib, ops
+    L = _lib.lib()
+    g = ops.make_geom(2, 64, 8, 384, 256, 179, 127, 64, 8, 2, 2.5, -3.5)
+    gv = ops.make_geom(2, 64, 8, 384, 256, 179, 127, 64, 8, 2, 2.5, -3.5, vd_dim=27)
+    P = ctypes.c_void_p(4096)   # a non-NULL stand-in
+    mp, gp_, rp = _lib.MlpParams(), _lib.MlpParams(), _lib.RenderParams()
+    need = L.n3dt_render_workspace_bytes(ctypes.byref(g), _lib.BF16)
+    EINVAL, EWS = -1, -2
+
+    def fwd(geom, prec, packed=P, ray_bias=None, ws=P, ws_bytes=None, fg=P, merge=None, bg=None):
+        return L.n3dt_render_fwd(ctypes.byref(geom) if geom is not None else None, prec, packed, ctypes.byref(mp), P, P, P, P, P, P, P, None, bg,
+                                 ray_bias, fg, P, None, None, merge, ws, ctypes.c_size_t(need if ws_bytes is None else ws_bytes), None)
+    assert fwd(None, _lib.BF16) == EINVAL and b"NULL" in L.n3dt_last_error()
+    assert fwd(g, 7) == EINVAL and b"precision" in L.n3dt_last_error()
+    assert fwd(g, _lib.BF16, packed=None) == EINVAL and b"n3dt_render_fwd" in L.n3dt_last_error()
+    assert fwd(g, _lib.BF16, ws_bytes=need - 1) == EWS and b"workspace too small" in L.n3dt_last_error()
+    assert fwd(g, _lib.BF16, ray_bias=P) == EINVAL and b"per-ray bias" in L.n3dt_last_error()
+    assert fwd(gv, _lib.BF16) == EINVAL and b"per-ray bias" in L.n3dt_last_error()
+    assert fwd(g, _lib.BF16, fg=None) == EINVAL and b"neither" in L.n3dt_last_error()
+    assert fwd(g, _lib.BF16, merge=P) == EINVAL and b"bg_featmap" in L.n3dt_last_error()
+    # training pair: saved buffer and workspace are sized by their own queries
+    sv, ws = L.n3dt_render_train_saved_bytes(ctypes.byref(g)), L.n3dt_render_train_workspace_bytes(ctypes.byref(g))
+    a14 = [P] * 14
+    a14[9] = None   # ray_bias (vd_dim == 0)
+    train = lambda sv_b, ws_b, a=a14: L.n3dt_render_train_fwd(ctypes.byref(g), _lib.BF16, P, ctypes.byref(mp), *a, P, ctypes.c_size_t(sv_b),  # noqa: E731
+                                                              P, ctypes.c_size_t(ws_b), None)
+    assert train(sv - 1, ws) == EWS and b"saved buffer too small" in L.n3dt_last_error()
+    assert train(sv, ws - 1) == EWS and b"workspace too small" in L.n3dt_last_error()
+    assert train(sv, ws, [P] * 14) == EINVAL and b"per-ray bias" in L.n3dt_last_error()
+    # the 2-D renderer: workspace, then the saved buffer of its training forward
+    nrws = L.n3dt_neural_render_workspace_bytes(ctypes.byref(g), 2)
+    assert L.n3dt_neural_render_fwd(ctypes.byref(g), 2, _lib.BF16, ctypes.byref(rp), P, P, P, ctypes.c_size_t(nrws - 1), None) == EWS
+    assert b"workspace too small" in L.n3dt_last_error()
+    assert L.n3dt_neural_render_fwd(None, 2, _lib.BF16, ctypes.byref(rp), P, P, P, ctypes.c_size_t(nrws), None) == EINVAL
+    # the stand-alone seams
+    assert L.n3dt_embed(0, ctypes.c_size_t(16), P, P, None) == EINVAL and b"n3dt_embed" in L.n3dt_last_error()   # an empty batch
+    assert L.n3dt_mlp_points(ctypes.byref(g), ctypes.c_size_t(64), ctypes.byref(mp), P, P, P, P, P, P, ctypes.c_size_t(0), None) == EWS
+    assert b"n3dt_mlp_points" in L.n3dt_last_error()
