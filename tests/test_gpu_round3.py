@@ -198,7 +198,7 @@ def test_bf16_and_fp32_training_converge_to_the_same_loss():
     same weights, data and stratified jitter, once with train_precision="fp32" (the exact path pinned to the reference's
     autograd) and once with "bf16": the loss curves stay within 2 % of each other at steps 50 / 100 (measured: 0.01 %) and within
     10 % at step 200 (measured: bf16 4 - 8 % lower, after a 160-fold fall of the loss; two fp32 runs differ by 0.3 - 4 % there) and the images the two
-    trained networks render (exact fp32 inference) agree within 5e-3 on average (99 % of the pixels within 0.1: see the end)."""
+    trained networks render (exact fp32 inference) agree within 1e-2 on average (99 % of the pixels within 0.15: see the end)."""
     from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
     from n3dt.train import fused_data_losses, disk_mask
     opt = BaseOptions({"featmap_size": 32, "featmap_nc": 256, "pred_img_size": 256, "num_sample_coarse": 64})
@@ -256,10 +256,12 @@ def test_bf16_and_fp32_training_converge_to_the_same_loss():
     print("final images, bf16 vs fp32 : mean |diff| %.2e, median %.2e, p99 %.2e, max %.2e" % s16)
     print("final images, fp32 vs fp32 : mean |diff| %.2e, median %.2e, p99 %.2e, max %.2e" % s32)
     # Two 200-step trajectories are not pixel-identical even in the SAME arithmetic (second line: fp32 atomics sum in a different
-    # order each run): part of the image is still moving fast at step 200 (mask edge; measured over five boxes: p99 of the
-    # bf16-vs-fp32 difference 2.7e-2 .. 8.1e-2 while two fp32 runs differ by 0.9e-2 .. 1.2e-2 there).  The bf16 run must stay
-    # within 5e-3 on average, and 99 % of its pixels within 0.1, of the fp32 run beyond three times that floor.
-    assert s16[0] <= 5e-3 + 3.0 * s32[0] and s16[2] <= 0.1 + 3.0 * s32[2]
+    # order each run): part of the image is still moving fast at step 200 (mask edge).  Eight repetitions of this test in one
+    # process (tools/converge_spread_probe.py, profiles/r04_q_converge_spread_8runs.log): bf16 vs fp32 mean 1.8e-3 .. 6.7e-3,
+    # p99 3.2e-2 .. 1.0e-1; two fp32 runs against each other mean 3.5e-4 .. 3.7e-3, p99 6.0e-3 .. 7.5e-2 -- the same order, and a
+    # "floor" that itself moves tenfold from draw to draw.  (Round 3 bounded the bf16 figure by 5e-3 + 3 x THIS run's fp32 floor;
+    # with a low draw of the floor that failed in 1 run of 8.)  Fixed bounds at 1.5 x the worst of those eight runs:
+    assert s16[0] <= 1.0e-2 and s16[2] <= 0.15
 
 
 @pytest.mark.parametrize("train_precision", ["fp32", "bf16"])
