@@ -94,7 +94,11 @@ def test_whole_training_step_replays_as_one_graph():
     moved = 0.0
     for (n, a), (_, b) in zip(net_e.named_parameters(), net_g.named_parameters()):
         d0 = float((a - b).abs().max())
-        assert d0 <= 2.5e-4, (n, d0)  # far below the 1.2e-3 a parameter travelled
+        # Ten repetitions (tools/graph_step_spread_probe.py, profiles/r04_q_graph_step_spread_10runs.log): the largest difference
+        # between TWO EAGER runs is 1.0e-4 .. 3.0e-4 and between an eager and a graphed run 1.0e-4 .. 3.0e-4 -- one distribution
+        # (Adam moves a weight whose gradient is summation-order noise by up to lr per step either way).  2 x its worst draw,
+        # half of the 1.2e-3 a parameter travelled (round 4's first bound, 2.5e-4, sat inside the distribution: 2 draws of 20 above)
+        assert d0 <= 6e-4, (n, d0)
         moved = max(moved, d0)
     # the second optimizer ran inside the graph too: 9 replays x lr 1e-7 on a constant gradient
     assert float(bucket_g.flat.detach().abs().max()) > 5e-7
