@@ -32,6 +32,10 @@ def test_rccl_one_rank_group_reduces_both_buckets_in_order(tmp_path):
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
+    import socket
+    with socket.socket() as sock:   # a free rendezvous port (the worker's default is a fixed one)
+        sock.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(sock.getsockname()[1])
     r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_rccl_worker.py"), out], env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, "worker failed:\n%s\n%s" % (r.stdout[-2000:], r.stderr[-4000:])
