@@ -16,7 +16,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import _lib, ops, synthetic
+from . import _lib, ops
 from .parallel import _graph_task_id as parallel_graph_task_id
 
 

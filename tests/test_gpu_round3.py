@@ -8,8 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, synthetic_case
-from test_gpu_parity import dev, to_dev, build_net, fwd, feats, FEAT_TOL
+from test_gpu_parity import dev, to_dev, build_net, feats, FEAT_TOL
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,9 +1,7 @@
 #!/usr/bin/env python3
 """Print HIP-vs-golden error magnitudes for every fixture and precision (run on the GPU box)."""
-import json
 import os
 import sys
-import time
 
 import numpy as np
 import torch
