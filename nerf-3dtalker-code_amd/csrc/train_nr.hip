@@ -671,6 +671,12 @@ __global__ __launch_bounds__(256, (TO * TI >= 8 && (PM == 1 || nrt_dw16_is_rows<
     const bool do_rs = db != nullptr && (blockIdx.y % tiles_i) == 0;
     // channels past the layer's width (a 64 x 128 wave tile on a narrower layer) are clamped to a valid one: their tiles are
     // computed and dropped.  The main loop takes whole 16-pixel steps with no per-element guards, two steps in flight.
+    // One 16-pixel step: ALL its loads first (2-byte gathers: lane r takes channel r of 8 consecutive pixels), then the TO x TI
+    // products, then the bias row sums.  (With the row sums between the dY loads and the X loads, as first written, the X loads
+    // waited for them: 80 / 54 / 57 / 34 us per launch of a config-3 step became 77 / 49 / 47 / 30; summing before the products
+    // instead costs the 2 x 4-tile float-map instantiation a 16-byte spill.  Measured and dropped: the loads of step k + 1 issued
+    // before the products of step k, raw values converted at use -- 78 us either way for the 1 x 2-tile instantiation: these
+    // kernels are bound by the rate of the 2-byte gathers, not by a step's latency.)
     auto step = [&](const long p, const bool guard) {
         nrt_bf16x8 fa[TO], fb[TI];
         const long pb = p + 8 * h;
@@ -681,12 +687,6 @@ __global__ __launch_bounds__(256, (TO * TI >= 8 && (PM == 1 || nrt_dw16_is_rows<
 #pragma unroll
             for (int j = 0; j < 8; ++j) u[j] = (!guard || pb + j < p1) ? dY[(pb + j) * co + ch].u : (unsigned short)0;
             fa[a] = __builtin_bit_cast(nrt_bf16x8, u);
-            if (do_rs) {
-                float t = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) t += (float)fa[a][j];
-                rs[a] += t;
-            }
         }
 #pragma unroll
         for (int b = 0; b < TI; ++b) {
@@ -703,6 +703,15 @@ __global__ __launch_bounds__(256, (TO * TI >= 8 && (PM == 1 || nrt_dw16_is_rows<
         for (int a = 0; a < TO; ++a)
 #pragma unroll
             for (int b = 0; b < TI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        if (do_rs) {  // (after the products: the X fragments are dead by now)
+#pragma unroll
+            for (int a = 0; a < TO; ++a) {
+                float t = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t += (float)fa[a][j];
+                rs[a] += t;
+            }
+        }
     };
     long p = p0;
     for (; p + 16 <= p1; p += 16) step(p, false);
