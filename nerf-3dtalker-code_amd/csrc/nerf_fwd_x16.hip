@@ -361,6 +361,14 @@ __device__ __forceinline__ void nerf_fwd_x16_body(
             }
         }
         float sigma = fmaxf(sp, 0.0f);
+#if defined(X16_DIAG_REMASK_DEAD_LANES)
+        // diagnostic builds only (docs/tuning_log.md, round 4: the cause of tiling 2's garbage): the lanes past N_s get their
+        // dist = 0 / zval = 0 again HERE, from the sample index, instead of trusting the registers that carried them from the
+        // prologue -- hipcc parked those in AGPRs with a copy that ran under the sampler's reduced lane mask
+        // (the values are made opaque first: the compiler KNOWS they are 0 in those lanes and folds a plain select away)
+        asm volatile("" : "+v"(dist[nb]), "+v"(zval[nb]));
+        if ((int)(blk[nb] % bpr) * X16_BS + c >= g.n_samples) dist[nb] = 0.0f, zval[nb] = 0.0f;
+#endif
         float alpha = 1.0f - expf(-sigma * dist[nb]);
         float x = 1.0f - alpha + 1e-10f;
         float Tl = n3dt_exclusive_prod<32>(x, c);

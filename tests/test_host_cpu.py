@@ -177,6 +177,30 @@ def test_stream_hazard_scanner_flags_scalar_and_flat_accesses(tmp_path):
         assert len(mod.scan_inflight(str(f))) == n, name
 
 
+def test_scanner_flags_a_register_copy_placed_before_the_exec_restore_of_a_join(tmp_path):
+    """Round 4's root cause of the withdrawn tiling 2 (docs/tuning_log.md): hipcc put the VGPR -> AGPR copies of two values that
+    are live across a divergent region (`dist`, `zval` of n3dt_sample_point: 0 for the lanes past N_s) at the region's join label,
+    BEFORE the `s_or_b64 exec` -- so they ran for the region's lanes only and the other lanes of the AGPRs kept stale contents.
+    scan_join_copies() finds exactly that shape (the assembly below is the failing build's, shortened) and not its correct form."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_smem_hazard", os.path.join(REPO, "tools", "check_smem_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    head = ("_Z1kv:\n\tv_mov_b32_e32 v4, 0\n\tv_cmp_gt_i32_e32 vcc, s66, v0\n\ts_and_saveexec_b64 s[44:45], vcc\n"
+            "\ts_cbranch_execz .LBB1_55\n\tv_mul_f32_e32 v4, v2, v4\n.LBB1_55:\n")
+    bad = head + "\tv_writelane_b32 v254, s82, 17\n\tv_accvgpr_write_b32 a33, v4\n\ts_or_b64 exec, exec, s[44:45]\n\ts_endpgm\n"
+    good = head + "\tv_writelane_b32 v254, s82, 17\n\ts_or_b64 exec, exec, s[44:45]\n\tv_accvgpr_write_b32 a33, v4\n\ts_endpgm\n"
+    inside = ("_Z1kv:\n\ts_and_saveexec_b64 s[44:45], vcc\n\ts_cbranch_execz .LBB1_5\n\tv_accvgpr_write_b32 a3, v4\n.LBB1_5:\n"
+              "\ts_or_b64 exec, exec, s[44:45]\n\ts_endpgm\n")   # a value made INSIDE the region may be parked there
+    for name, text, n in (("bad", bad, 1), ("good", good, 0), ("inside", inside, 0)):
+        f = tmp_path / (name + ".s")
+        f.write_text(text)
+        found = mod.scan_join_copies(str(f))
+        assert len(found) == n, (name, found)
+    hit = mod.scan_join_copies(str(tmp_path / "bad.s"))[0]
+    assert hit[0] == "_Z1kv" and hit[1] == ".LBB1_55" and hit[3] == "v_accvgpr_write_b32 a33, v4"
+
+
 def _shipped_asm():
     """build/*.s -- the device assembly the Makefile keeps next to every object.  build/ is git-ignored: a checkout without
     hipcc has none (conftest builds the library only where a compiler exists), and a gate on the shipped assembly has nothing
@@ -190,8 +214,8 @@ def _shipped_asm():
 
 def test_shipped_stream_kernels_pass_the_hazard_gate():
     """The static gate on the SHIPPED build: the Makefile keeps the device assembly of the very compile that produced the
-    objects linked into libn3dt.so (build/<name>.s, same FLAGS); scan() and scan_inflight() must find nothing in any
-    kernel of it -- every tiling of the fused render kernel (1, 2 and the 16x16x32 one), the training forward / dX chain /
+    objects linked into libn3dt.so (build/<name>.s, same FLAGS); scan(), scan_inflight() and scan_join_copies() must find nothing
+    in any kernel of it -- every tiling of the fused render kernel (1, 2 and the 16x16x32 one), the training forward / dX chain /
     weight-gradient kernels and every instantiation of the renderer's fused block kernel."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("check_smem_hazard", os.path.join(REPO, "tools", "check_smem_hazard.py"))

@@ -9,6 +9,13 @@ kernel arguments lazily; kernels pin what they need up front (x16_pin) and this 
 A second check (scan_inflight) looks for anything that reads or writes a fragment's registers while its LDS read is still
 in flight.
 
+A third check (scan_join_copies) is for a code-generation fault of the compiler itself, found in round 4 in a diagnostic build of
+the 4-wave x 64-sample tiling (docs/tuning_log.md): a VGPR -> AGPR copy of a value that is live ACROSS a divergent region placed
+at the region's join label BEFORE the `s_or_b64 exec, exec, ...` that restores the lane mask.  The copy then runs for the
+region's lanes only and the other lanes of the AGPR keep whatever it held: `dist = 0` of the lanes past N_s was lost that way
+(they carried compositing weight, differently from run to run).  No shipped kernel may contain the pattern; it runs over EVERY
+kernel of every file, not only the stream kernels.
+
 The scan runs on build/<name>.s, the device assembly the Makefile keeps from the compile that produced the shipped objects
 (same FLAGS, -save-temps=obj), for every source file: all tilings and the training kernels included.
 
@@ -108,6 +115,32 @@ def scan_inflight(path):
     return bad
 
 
+def scan_join_copies(path):
+    """AGPR writes between the join label of a divergent region (a target of s_cbranch_execz) and the EXEC restore that follows
+    it: they execute under the region's reduced lane mask.  Returns [(kernel, label, line offset in the kernel, instruction)]."""
+    text = open(path).read()
+    found = []
+    for m in re.finditer(r"^(_Z\w+):", text, re.M):
+        end = text.find("s_endpgm", m.end())
+        if end < 0:
+            continue
+        lines = [l.split(";")[0].rstrip() for l in text[m.end():end].split("\n")]
+        targets = set(re.findall(r"s_cbranch_execz\s+(\.LBB\d+_\d+)", "\n".join(lines)))
+        for i, l in enumerate(lines):
+            lab = l.strip().rstrip(":")
+            if not l.strip().endswith(":") or lab not in targets:
+                continue
+            for j in range(i + 1, len(lines)):
+                t = lines[j].strip()
+                if not t:
+                    continue
+                if re.match(r"s_(or|mov)_b64 exec\b", t) or t.endswith(":") or t.startswith(("s_cbranch", "s_branch", "s_setpc")):
+                    break
+                if t.startswith(("v_accvgpr_write", "v_accvgpr_mov")):
+                    found.append((m.group(1), lab, j, t))
+    return found
+
+
 def stream_kernels(path):
     """Names of the kernels in an assembly file that contain an inline-asm fragment read (the stream kernels)."""
     names, name = [], None
@@ -144,6 +177,8 @@ def check_shipped(verbose=True):
             findings.append("%s: %s: scalar/flat access %d lines after the first stream read: %s" % (src, name, off, ins))
         for name, off, ins in scan_inflight(path):
             findings.append("%s: %s: touches a fragment still in flight (read issued %d lines earlier): %s" % (src, name, off, ins))
+        for name, lab, off, ins in scan_join_copies(path):
+            findings.append("%s: %s: `%s` (%s + %d lines) runs before the EXEC restore of the region it joins" % (src, name, ins, lab, off))
         if verbose:
             print("%s: scanned (%d stream kernels)" % (src, len(kernels[src])))
     return findings, kernels
