@@ -478,3 +478,65 @@ def test_two_threads_two_streams_two_networks():
         assert torch.equal(a["img"], b["img"])
         assert abs(a["loss"] - b["loss"]) <= 1e-4 * abs(a["loss"])
         assert float((a["g"] - b["g"]).abs().max()) <= 2e-2 * float(a["g"].abs().max())   # fp32 atomics of the bf16 path
+
+
+def _dirty_the_register_files():
+    """Leave NaNs in the vector and accumulator registers (and LDS) of every CU: large fp32 / bf16 / fp16 GEMMs of NaN matrices
+    (the BLAS kernels keep their accumulators in AGPRs and stage tiles through LDS) and an elementwise pass."""
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        x = torch.full((4096, 4096), float("nan"), device=dev(), dtype=dt)
+        y = x @ x
+        y = torch.sin(y) + x
+    torch.cuda.synchronize()
+    del x, y
+
+
+@pytest.mark.parametrize("ns", [8, 40, 65])
+def test_results_do_not_depend_on_what_the_registers_held(ns):
+    """Round 4 found a build (the withdrawn 64-sample tiling under diagnostic flags) whose lanes past N_s read stale accumulator
+    registers: right in a fresh process, wrong once other kernels had run on the CU (docs/tuning_log.md: hipcc parked two values in
+    AGPRs under a reduced lane mask).  The static gate looks for that code shape; this is the dynamic side: every precision of the
+    inference path and both training paths, at sample counts that leave 24 / 24 / 31 dead lanes in the last 32-sample block, give
+    the SAME result after the register files of the whole chip were filled with NaNs (bit-identical for inference, fp32-atomic
+    noise for the gradients)."""
+    from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
+    from n3dt.train import fused_data_losses, disk_mask
+    opt = BaseOptions({"featmap_size": 12, "featmap_nc": 256, "pred_img_size": 48, "num_sample_coarse": ns})
+    sd = syn.make_state_dict(opt, seed=3, bg_noise=0.1)
+    d = to_dev(syn.frame_inputs(opt, 3))
+    a = (d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"], d["batch_Tvecs"],
+         d["batch_inv_inmats"])
+    t_rand = syn.stratified_noise(3, 144, ns, seed=5).to(dev())
+    gt, mask = torch.full((3, 3, 48, 48), 0.5, device=dev()), disk_mask(3, 48).to(dev())
+
+    def everything():
+        out = {}
+        for prec in ("bf16", "fp16", "bf16x3", "fp32"):
+            net = HeadNeRFNet(opt, False, False, precision=prec).to(dev())
+            net.load_state_dict(sd, strict=True)
+            with torch.no_grad():
+                out["img_" + prec] = net("test", *a)["coarse_dict"]["merge_img"].clone()
+                f = net.render_features(d["batch_xy"], d["audiostyle"], d["shape_code"], d["appea_code"], d["batch_Rmats"], d["batch_Tvecs"],
+                                        d["batch_inv_inmats"], t_rand=t_rand, want_depth=True, want_weight=True)
+                for k in ("fg_feat", "bg_alpha", "depth", "weight"):
+                    out["%s_%s" % (k, prec)] = f[k].clone()
+        for tp in ("fp32", "bf16"):
+            net = HeadNeRFNet(opt, False, False, train_precision=tp).to(dev())
+            net.load_state_dict(sd, strict=True)
+            loss = fused_data_losses(net("train", *a, t_rand=t_rand)["coarse_dict"], gt, mask)["total_loss"]
+            loss.backward()
+            out["loss_" + tp] = loss.detach().clone()
+            out["g7_" + tp] = net.fg_CD_predictor.FeaExt_module_7.weight.grad.detach().clone()
+            out["gd_" + tp] = net.fg_CD_predictor.density_module.weight.grad.detach().clone()
+        torch.cuda.synchronize()
+        return out
+    clean = everything()
+    _dirty_the_register_files()
+    dirty = everything()
+    for k in clean:
+        assert torch.isfinite(dirty[k]).all(), k
+        if k.startswith(("g7_", "gd_", "loss_")):
+            scale = float(clean[k].abs().max()) + 1e-30
+            assert float((clean[k] - dirty[k]).abs().max()) <= 2e-2 * scale, k
+        else:
+            assert torch.equal(clean[k], dirty[k]), (k, float((clean[k].float() - dirty[k].float()).abs().max()))
