@@ -540,3 +540,53 @@ def test_results_do_not_depend_on_what_the_registers_held(ns):
             assert float((clean[k] - dirty[k]).abs().max()) <= 2e-2 * scale, k
         else:
             assert torch.equal(clean[k], dirty[k]), (k, float((clean[k].float() - dirty[k].float()).abs().max()))
+
+
+def test_hierarchical_and_view_direction_paths_do_not_depend_on_register_contents():
+    """The same dirty-register check for the kernels the first test does not reach: the fine-sampling kernel and the fine pass
+    (hier_sampling=True), the per-ray view-direction bias (include_vd=True), the gaze-extended shape code, and the frozen-network
+    backward of single-image fitting -- at a sample count with dead lanes (N_c = 20, N_f = 13: 33 planes)."""
+    from n3dt import BaseOptions, HeadNeRFNet, synthetic as syn
+    from n3dt.train import data_losses, disk_mask
+    opt = BaseOptions({"featmap_size": 10, "featmap_nc": 256, "pred_img_size": 40, "num_sample_coarse": 20, "num_sample_fine": 13})
+
+    def everything():
+        out = {}
+        for name, kw, sdkw in (("hier", dict(include_vd=False, hier_sampling=True), dict(hier_sampling=True)),
+                               ("vd", dict(include_vd=True, hier_sampling=False), dict(include_vd=True)),
+                               ("gaze", dict(include_vd=False, hier_sampling=False, include_gaze=True, eye_gaze_dim=64),
+                                dict(include_gaze=True, eye_gaze_dim=64))):
+            d = to_dev(syn.frame_inputs(opt, 2, **{k: v for k, v in sdkw.items() if k in ("include_gaze", "eye_gaze_dim")}))
+            a = (d["batch_xy"], d["batch_uv"], d["audiostyle"], None, d["shape_code"], d["appea_code"], d["batch_Rmats"], d["batch_Tvecs"],
+                 d["batch_inv_inmats"])
+            for prec in ("bf16", "fp32"):
+                net = HeadNeRFNet(opt, precision=prec, **kw).to(dev())
+                net.load_state_dict(syn.make_state_dict(opt, seed=4, bg_noise=0.1, **sdkw), strict=True)
+                with torch.no_grad():
+                    o = net("test", *a)
+                for part in o:
+                    out["%s_%s_%s" % (name, prec, part)] = o[part]["merge_img"].clone()
+            # fitting: frozen network, gradients to codes and cameras (exact fp32 path)
+            net = HeadNeRFNet(opt, train_precision="fp32", **kw).to(dev())
+            net.load_state_dict(syn.make_state_dict(opt, seed=4, bg_noise=0.1, **sdkw), strict=True)
+            for p in net.parameters():
+                p.requires_grad_(False)
+            leaf = {k: d[k].clone().requires_grad_(True) for k in ("shape_code", "appea_code", "batch_Rmats", "batch_Tvecs")}
+            o = net("test", d["batch_xy"], d["batch_uv"], d["audiostyle"], None, leaf["shape_code"], leaf["appea_code"], leaf["batch_Rmats"],
+                    leaf["batch_Tvecs"], d["batch_inv_inmats"])
+            last = o["fine_dict"] if "fine_dict" in o else o["coarse_dict"]
+            t = data_losses(last, torch.full_like(last["merge_img"], 0.5), disk_mask(2, 40).to(dev()))
+            (t["head_loss"] + t["nonhead_loss"]).backward()
+            for k, v in leaf.items():
+                out["%s_d_%s" % (name, k)] = v.grad.detach().clone()
+        torch.cuda.synchronize()
+        return out
+    clean = everything()
+    _dirty_the_register_files()
+    dirty = everything()
+    for k in clean:
+        assert torch.isfinite(dirty[k]).all(), k
+        if "_d_" in k:
+            assert float((clean[k] - dirty[k]).abs().max()) <= 1e-3 * float(clean[k].abs().max()) + 1e-12, k   # fp32 atomics
+        else:
+            assert torch.equal(clean[k], dirty[k]), (k, float((clean[k] - dirty[k]).abs().max()))
