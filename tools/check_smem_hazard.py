@@ -134,7 +134,8 @@ def scan_join_copies(path):
                 t = lines[j].strip()
                 if not t:
                     continue
-                if re.match(r"s_(or|mov)_b64 exec\b", t) or t.endswith(":") or t.startswith(("s_cbranch", "s_branch", "s_setpc")):
+                if re.match(r"s_(or|mov)_b64 exec\b", t) or re.match(r"s_\w+_saveexec_b64", t) or t.endswith(":") or \
+                        t.startswith(("s_cbranch", "s_branch", "s_setpc")):
                     break
                 if t.startswith(("v_accvgpr_write", "v_accvgpr_mov")):
                     found.append((m.group(1), lab, j, t))
